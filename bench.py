@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Throughput of the SOS hot path: columns/s to 1e-4 convergence at (N_tau=200, N_mu=128).
+
+One step = one pass of the hot path (I1 -> [Jn -> In] x orders, convergence test included) over
+one batch of synthetic columns whose inputs are already resident in HBM.  The workload is the
+BASELINE C4 sweep shape: 512 columns = 8 mu0 x 8 tau*_aer x 8 grd_alb, L=200, N=128, Rayleigh
+atmosphere + HG(g=0.7) aerosol stand-in (the EVA log-normal Mie phase function needs miepython,
+unavailable offline), specular surface, fp64.  With N GPUs every rank solves its own 512-column
+sweep (weak scaling; rank r uses a different aerosol single-scattering albedo) and the TOA /
+surface radiances and order counts are gathered to rank 0 over RCCL once per step.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sos-radiative-transfer_amd"))
+
+import numpy as np
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix, vendor datasheet; the microarch guide lists no f64 row
+
+
+def build_sweep(n_columns, L, N, rank, world):
+    from sosrt import inputs
+    side = max(1, round(n_columns ** (1 / 3)))
+    mu0 = np.linspace(0.2, 1.0, side)
+    taer = np.geomspace(0.01, 1.0, side)
+    rho = np.linspace(0.0, 0.8, side)
+    M0, TA, RH = (x.ravel()[:n_columns] for x in np.meshgrid(mu0, taer, rho, indexing="ij"))
+    B = len(M0)
+    mu = inputs.direction_grid(N)
+    iu, idn = inputs.slab_indices(120, 25, 17, L)
+    tau_atm = 0.124
+    alb_aer = float(np.linspace(0.97, 0.90, world)[rank]) if world > 1 else 0.97
+    tau = np.stack([inputs.tau_profile(tau_atm, t, 120, 25, 17, L) for t in TA])
+    P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
+    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    cache = {}
+    for m in np.unique(M0):
+        cache[float(m)] = (inputs.phase_function("rayleigh", N, mu, m)[0], inputs.phase_function("hg", N, mu, m, 0.7)[0])
+    P0a = np.stack([cache[float(m)][0] for m in M0])
+    P0r = np.stack([cache[float(m)][1] for m in M0])
+    return dict(B=B, L=L, N=N, mu=mu, tau=tau, P_atm=P_atm, P_aer=P_aer, P0a=P0a, P0r=P0r, mu0=M0, taer=TA, rho=RH,
+                idx_up=iu, idx_down=idn, tau_atm=tau_atm, alb_aer=alb_aer)
+
+
+def cpu_baseline(w, seconds_budget=25.0):
+    """The oracle in its literal (reference-cost) mode on one host core, on a bounded sample of the
+    same sweep: columns are taken evenly across the sweep until the budget is used."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sos_oracle as O
+    B = w["B"]
+    order = np.linspace(0, B - 1, min(B, 8)).astype(int)
+    done, orders, t0 = 0, 0, time.perf_counter()
+    for b in order:
+        col = O.Column(tau=w["tau"][b], mu=w["mu"], N=w["N"], idx_up=w["idx_up"], idx_down=w["idx_down"], mu0=float(w["mu0"][b]),
+                       grd_alb=float(w["rho"][b]), alb_atm=1.0, alb_aer=w["alb_aer"], dtau_atm=w["tau_atm"] / w["L"],
+                       dtau_aer=float(w["taer"][b]) / (w["idx_down"] + 1 - w["idx_up"]),
+                       tauStar_tot=w["tau_atm"] + float(w["taer"][b]), P0_atm=w["P0a"][b], P_atm=w["P_atm"],
+                       P0_aer=w["P0r"][b], P_aer=w["P_aer"])
+        s = O.solve_column(col, literal=True)
+        done += 1
+        orders += s.n - 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "columns/s", "cores": 1, "kind": "port",
+            "sample": "%d columns of the same sweep (evenly spaced), %d orders, oracle literal mode, %.1f s" % (done, orders, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--columns", type=int, default=512, help="columns per GPU")
+    ap.add_argument("--layers", type=int, default=200)
+    ap.add_argument("--angles", type=int, default=128)
+    ap.add_argument("--max-orders", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from sosrt import _lib
+    from sosrt.solver import Solver
+
+    w = build_sweep(a.columns, a.layers, a.angles, rank, world)
+    B, L, N = w["B"], w["L"], w["N"]
+    D = 2 * N
+    s = Solver(L, N, max_batch=B, max_orders=a.max_orders, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    s.set_stream(stream.cuda_stream)
+    s.set_grid(w["mu"])
+    s.set_phase(w["P_atm"], w["P_aer"])
+    s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
+                  w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
+    d_tau = torch.from_numpy(w["tau"]).to(dev)
+    d_P0a = torch.from_numpy(w["P0a"]).to(dev)
+    d_P0r = torch.from_numpy(w["P0r"]).to(dev)
+    d_I = torch.empty((B, L, D), dtype=torch.float64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    digest_bufs = None
+
+    def step():
+        s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), tol=1e-4,
+                       d_n_orders=d_n.data_ptr(), d_status=d_st.data_ptr())
+        if world > 1:
+            # the only collective: gather of the per-column digests to rank 0
+            dig = torch.cat([d_I[:, 0, N:], d_I[:, L - 1, :N], d_n.to(torch.float64)[:, None]], dim=1).contiguous()
+            bufs = [torch.empty_like(dig) for _ in range(world)] if rank == 0 else None
+            dist.gather(dig, bufs, dst=0)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    s.profile_enable(True)
+    s.profile_reset()
+    sum_orders = 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        sum_orders += 0      # orders are read back after the timed region (same every step)
+    sync_all()
+    dt = time.perf_counter() - t0
+    n_host = d_n.cpu().numpy()
+    st_host = d_st.cpu().numpy()
+    orders_per_step = int((n_host - 1).sum())
+    gemm_ms, gemm_launches = s.profile_get(_lib.K_GEMM)
+    tr_ms, tr_launches = s.profile_get(_lib.K_TRANSPORT)
+    fo_ms, _ = s.profile_get(_lib.K_FIRST)
+    s.profile_enable(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        # dominant kernel: the Jn contraction.  Algorithmic flops per launch group = 2 L D^2 per live
+        # (column, order) pair (no credit for the second slab matrix or for padding).
+        flops = 2.0 * L * D * D * orders_per_step * a.steps
+        achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "SOS columns/sec to 1e-4 convergence (Ntau=200, Nmu=128)",
+            "value": value, "unit": "columns/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4 sweep: %d columns/GPU = mu0 x tau*_aer x grd_alb grid, L=%d, N=%d (D=%d), "
+                                   "Rayleigh atm + HG(0.7) aerosol stand-in, specular surface, tol 1e-4" % (B, L, N, D),
+                       "columns_per_gpu": B, "orders_per_step": orders_per_step, "max_order": int(n_host.max()),
+                       "not_converged": int((st_host != 0).sum()), "parallelism": "columns sharded x%d, gather only" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_jn_gemm", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": gemm_ms / max(gemm_launches, 1), "launches": gemm_launches},
+            "kernel_ms_per_step": {"k_jn_gemm": gemm_ms / a.steps, "k_transport": tr_ms / a.steps,
+                                   "k_first_order": fo_ms / a.steps},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

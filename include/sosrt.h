@@ -1,0 +1,151 @@
+/*
+ * sosrt.h -- C ABI of libsosrt.so, the MI355X (gfx950) implementation of the
+ * Successive-Orders-of-Scattering hot path of
+ * Guillaume-SOULIER/SOS-Radiative-Transfer (reference snapshot 2025-09-05).
+ *
+ * The reference has no FFI layer: its boundary for this path is a set of plain
+ * Python functions on caller-owned float64 NumPy arrays.  Each entry point
+ * below names the reference interface it replaces (file:line, relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SOSRT_E_* code on error;
+ *     sosrt_last_error() returns a message for the calling thread.
+ *   - all floating-point data is IEEE double, row-major, index order
+ *     [column][order][layer t][direction m], m fastest; directions
+ *     are ordered mu = -1..0 (m = 0..N-1, downward) then 0..+1 (m = N..2N-1).
+ *   - "host" entry points take host pointers and copy in/out; "_dev" entry
+ *     points take device pointers (hipMalloc'd, resident) and only enqueue
+ *     work on the handle's stream.
+ *   - a handle is bound to one device and one stream and is not thread-safe;
+ *     distinct handles may be used concurrently.
+ *   - the caller owns every buffer passed in.
+ */
+#ifndef SOSRT_H
+#define SOSRT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sosrt_handle sosrt_t;
+
+#define SOSRT_OK              0
+#define SOSRT_E_INVALID      -1   /* bad argument / shape (Python layer raises ValueError)   */
+#define SOSRT_E_HIP          -2   /* HIP runtime error                                        */
+#define SOSRT_E_STATE        -3   /* call order (grid / phase / columns not set)              */
+#define SOSRT_E_NOMEM        -4
+
+/* per-column status written by transport / solve */
+#define SOSRT_COL_OK           0
+#define SOSRT_COL_INDEXERROR   1  /* upward mu->0+ search ran off the grid: the reference raises IndexError (spec:404, I1_In:103) */
+#define SOSRT_COL_MAXORDERS    2  /* not converged within max_orders                                                          */
+
+/* geometry of a column */
+#define SOSRT_GEOM_THREE_ZONE  0  /* above / inside / below the aerosol slab: SOS_Aer_main_specular.py:104-458 */
+#define SOSRT_GEOM_SINGLE_SLAB 1  /* one homogeneous slab, black surface:      SOS_Aer_I1_In.py:13-130           */
+
+/* surface model for orders n >= 2 */
+#define SOSRT_SURFACE_NONE       0  /* single slab (I1_In:86-98)                                       */
+#define SOSRT_SURFACE_SPECULAR   1  /* spec:397/399                                                    */
+#define SOSRT_SURFACE_LAMBERTIAN 2  /* lam:399/401, coded sign (SURVEY hazard H2)                      */
+
+const char* sosrt_last_error(void);
+int sosrt_version(void);
+
+/* ---- handle ------------------------------------------------------------------------------- */
+/* L = nb_layers, N = nb_angles per hemisphere (spec:33,57).  Buffers are sized for max_batch
+ * columns; max_orders bounds the order loop of spec:309.  device < 0 makes a host-only handle
+ * (plan queries only, no GPU is touched). */
+int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_t** out);
+int sosrt_destroy(sosrt_t* h);
+/* run on a caller-provided hipStream_t (e.g. the current torch stream); NULL = the handle's own */
+int sosrt_set_stream(sosrt_t* h, void* hip_stream);
+int sosrt_synchronize(sosrt_t* h);
+
+/* ---- per-sweep setup ------------------------------------------------------------------------ */
+/* direction grid mu[2N] (spec:59-61).  Builds the trapezoid weights of np.trapz(.., mu) used by
+ * Jn (I1_In:73), the small-mu lane list (gva:5-7) and the extrapolation tables that replace
+ * improved_limit_mu_down (In_limit:113-141). */
+int sosrt_set_grid(sosrt_t* h, const double* mu);
+/* phase matrices P(mu, mu') [2N x 2N] (outputs of phase_func, phase:12); P_aer may be NULL for the
+ * single-slab geometry.  Folded on the host into W[k][m] = w_k P[m][2N-1-k] (I1_In:73, spec:321). */
+int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer);
+
+/* per-column scalars (the locals of spec:23-53).  Arrays have B entries.
+ *   THREE_ZONE : idx_up, idx_down (spec:40), mu0, grd_alb, alb_atm, alb_aer, dtau_atm, dtau_aer
+ *                (spec:50-53), tauStar_tot (spec:36).
+ *   SINGLE_SLAB: idx_* ignored (may be NULL); alb_atm = alb, tauStar_tot = tauStar of
+ *                I1_NumInt / In_NumInt (I1_In:13,77); grd_alb, alb_aer, dtau_* ignored (may be NULL). */
+int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface,
+                      const int* idx_up, const int* idx_down,
+                      const double* mu0, const double* grd_alb,
+                      const double* alb_atm, const double* alb_aer,
+                      const double* dtau_atm, const double* dtau_aer,
+                      const double* tauStar_tot);
+
+/* ---- step level (host pointers): parity surface of SOS_Aer_I1_In.py ------------------------- */
+/* I1_NumInt (I1_In:13) / three-zone first order (spec:104-292).
+ * tau [B][L], P0_atm / P0_aer [B][2N] (P0_aer may be NULL for SINGLE_SLAB), I1 out [B][L][2N] */
+int sosrt_first_order(sosrt_t* h, int B, const double* tau, const double* P0_atm, const double* P0_aer,
+                      double* I1_out);
+/* Jn_NumInt (I1_In:62) / spec:314-323.  In_1 [B][L][2N] -> Jn [B][L][2N] */
+int sosrt_source(sosrt_t* h, int B, const double* In_1, double* Jn_out);
+/* In_NumInt (I1_In:77) / spec:326-449 (+ lam:399/401).  Jn [B][L][2N] -> In [B][L][2N];
+ * status_out [B] receives SOSRT_COL_* (may be NULL). */
+int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, double* In_out, int* status_out);
+
+/* ---- column level: the order loop of spec:301-458 ------------------------------------------- */
+/* Iterates I1 -> [Jn -> In] until max(In/I at TOA-up, In/I at surface-down) < tol (spec:309) per
+ * column.  Outputs: I_out [B][L][2N]; I_saved_out [B][max_orders][L][2N] or NULL (spec:304-305,458);
+ * n_orders_out [B] (the final n of spec:307-310); status_out [B] or NULL; I1_in (nullable,
+ * [B][L][2N]) replaces the computed first order (used to pin the Lambertian n>=2 path). */
+int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, const double* P0_aer,
+                double tol, const double* I1_in,
+                double* I_out, double* I_saved_out, int* n_orders_out, int* status_out);
+/* same with device pointers; asynchronous on the handle's stream except for the convergence
+ * polls.  n_orders_out / status_out are device int arrays (nullable). */
+int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_atm, const double* d_P0_aer,
+                    double tol, const double* d_I1_in,
+                    double* d_I_out, double* d_I_saved_out, int* d_n_orders_out, int* d_status_out);
+/* number of order iterations (max over the batch) and sum over columns of the last solve */
+int sosrt_last_solve_stats(sosrt_t* h, int* max_orders_run, long long* sum_orders);
+
+/* ---- fused epilogue (graphe:157-158, crit:377-382): fluxes from a radiance field ------------ */
+/* flux_down/up [B][L]; beam_norm 0: F0/(4 pi) (crit:380), 1: F0 (graphe:157). host pointers. */
+int sosrt_fluxes(sosrt_t* h, int B, const double* tau, const double* I, int beam_norm,
+                 double* flux_down, double* flux_up);
+
+/* ---- helper level (In_limit:70,113) on device, host pointers -------------------------------- */
+/* rows [R][N] of downward radiances; returns the idx rewritten values per row: out [R][idx] with
+ * out[r][i] = improved_limit_mu_down(rows[r], mu[:N], N, idx, i). */
+int sosrt_limit_mu_down(sosrt_t* h, int R, int idx, const double* rows, double* out);
+/* out[r] = improved_asymptotic_downward_radiance(J[r][:len[r]], tau[r][:len[r]], tau_t[r], mu[r]);
+ * J, tau are [R][stride]. */
+int sosrt_asymptotic_down(sosrt_t* h, int R, int stride, const int* len, const double* J, const double* tau,
+                          const double* tau_t, const double* mu, double* out);
+
+/* ---- plan introspection (host only, no GPU needed) ------------------------------------------ */
+int sosrt_plan_weights(sosrt_t* h, double* w_out /*2N*/);
+int sosrt_plan_fold(sosrt_t* h, int which /*0 atm, 1 aer*/, double* W_out /*2N x 2N, W[k][m]*/);
+/* a4b table for a given rewritten-angle count idx: s0 (first source lane), ns (sources),
+ * C_out [idx][ns] (ns <= 5). */
+int sosrt_plan_fix_table(sosrt_t* h, int idx, int* s0, int* ns, double* C_out);
+int sosrt_plan_fix_count(double tau_ref, int N);  /* I1_In:124-127 */
+
+/* ---- profiling: HIP-event timing of the dominant kernels on the handle's stream ------------- */
+#define SOSRT_K_GEMM      0
+#define SOSRT_K_TRANSPORT 1
+#define SOSRT_K_FIRST     2
+#define SOSRT_K_SMALLMU   3
+#define SOSRT_K_COUNT     4
+int sosrt_profile_enable(sosrt_t* h, int on);
+int sosrt_profile_reset(sosrt_t* h);
+/* total milliseconds and launch count since the last reset (synchronises the stream) */
+int sosrt_profile_get(sosrt_t* h, int kernel, double* total_ms, long long* launches, double* work /*flops or bytes*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOSRT_H */

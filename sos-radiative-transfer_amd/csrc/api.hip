@@ -1,0 +1,705 @@
+// C ABI of libsosrt.so (see include/sosrt.h).  Host logic only: argument checks, device
+// buffers, the order loop with lagged convergence polling, HIP-event profiling.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sosrt.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace sosrt;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(x)                                                                                        \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) return fail(SOSRT_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                           \
+    } while (0)
+
+constexpr int kProfPool = 8192;
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;          // pairs
+    std::vector<int> kind;
+    size_t used = 0;
+};
+}  // namespace
+
+struct sosrt_handle {
+    int device = -1, L = 0, N = 0, D = 0, max_batch = 0, max_orders = 0;
+    bool gpu = false;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    Plan plan;
+    bool have_grid = false, have_phase = false, have_aer = false, have_cols = false;
+    int B = 0, geom = 0, surface = 0;
+    std::vector<double> Wa_h, Wr_h;
+    Grid g{};
+    // device: grid / phase
+    double *d_mu = nullptr, *d_Wa = nullptr, *d_Wr = nullptr, *d_wfdn = nullptr, *d_wfup = nullptr;
+    FixTab* d_fix = nullptr;
+    int* d_small = nullptr;
+    // device: columns
+    int *d_idx_up = nullptr, *d_idx_down = nullptr;
+    double* d_scal = nullptr;            // 7 arrays of max_batch
+    ColDesc* d_desc = nullptr;
+    double *d_rca = nullptr, *d_rcr = nullptr;
+    int* d_slabrows = nullptr;
+    int nslab = 0;
+    // device: fields (internal)
+    double *d_tau = nullptr, *d_P0a = nullptr, *d_P0r = nullptr;
+    double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr;
+    // convergence
+    int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr;
+    double* d_ratio = nullptr;
+    int* h_poll = nullptr;               // pinned [2]
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    int last_max_orders = 0;
+    long long last_sum_orders = 0;
+    Prof prof;
+};
+
+namespace {
+
+size_t field_elems(const sosrt_handle* h) { return (size_t)h->max_batch * h->L * h->D; }
+
+template <class T>
+int dalloc(T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) return fail(SOSRT_E_NOMEM, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return 0;
+}
+
+void prof_begin(sosrt_handle* h, int kind) {
+    Prof& p = h->prof;
+    if (!p.on || p.used + 2 > p.ev.size()) return;
+    hipEventRecord(p.ev[p.used], h->stream);
+}
+void prof_end(sosrt_handle* h, int kind) {
+    Prof& p = h->prof;
+    if (!p.on || p.used + 2 > p.ev.size()) return;
+    hipEventRecord(p.ev[p.used + 1], h->stream);
+    p.kind[p.used / 2] = kind;
+    p.used += 2;
+}
+
+int need_gpu(sosrt_handle* h) {
+    if (!h) return fail(SOSRT_E_INVALID, "null handle");
+    if (!h->gpu) return fail(SOSRT_E_STATE, "handle was created host-only (device < 0)");
+    return 0;
+}
+
+Conv make_conv(sosrt_handle* h, double tol) {
+    Conv c;
+    c.active = h->d_active; c.norders = h->d_norders; c.status = h->d_status;
+    c.nactive = h->d_nactive; c.ratio = h->d_ratio; c.tol = tol;
+    return c;
+}
+
+int check_ready(sosrt_handle* h, int B, bool need_phase) {
+    if (int e = need_gpu(h)) return e;
+    if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
+    if (need_phase && !h->have_phase) return fail(SOSRT_E_STATE, "sosrt_set_phase has not been called");
+    if (!h->have_cols) return fail(SOSRT_E_STATE, "sosrt_set_columns has not been called");
+    if (B != h->B) return fail(SOSRT_E_INVALID, "B=%d does not match sosrt_set_columns (B=%d)", B, h->B);
+    if (need_phase && h->geom == SOSRT_GEOM_THREE_ZONE && !h->have_aer)
+        return fail(SOSRT_E_STATE, "three-zone geometry needs P_aer (sosrt_set_phase)");
+    return 0;
+}
+
+ColScalars scalars_of(sosrt_handle* h) {
+    ColScalars sc;
+    const size_t mb = h->max_batch;
+    sc.idx_up = h->d_idx_up; sc.idx_down = h->d_idx_down;
+    sc.mu0 = h->d_scal + 0 * mb; sc.rho = h->d_scal + 1 * mb; sc.alb_atm = h->d_scal + 2 * mb;
+    sc.alb_aer = h->d_scal + 3 * mb; sc.dtau_atm = h->d_scal + 4 * mb; sc.dtau_aer = h->d_scal + 5 * mb;
+    sc.T = h->d_scal + 6 * mb;
+    return sc;
+}
+
+// Jn for every row of the batch: main pass with W_atm, second pass over the slab rows with W_aer
+void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active) {
+    prof_begin(h, SOSRT_K_GEMM);
+    launch_gemm(h->stream, h->g, In_1, h->d_Wa, h->d_rca, nullptr, h->B * h->L, Jn, 0, active);
+    if (h->nslab > 0) launch_gemm(h->stream, h->g, In_1, h->d_Wr, h->d_rcr, h->d_slabrows, h->nslab, Jn, 1, active);
+    prof_end(h, SOSRT_K_GEMM);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sosrt_last_error(void) { return g_err.c_str(); }
+int sosrt_version(void) { return 100; }
+
+int sosrt_plan_fix_count(double tau_ref, int N) { return fix_count(tau_ref, N); }
+
+int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_t** out) {
+    if (!out) return fail(SOSRT_E_INVALID, "out is null");
+    *out = nullptr;
+    if (L < 2) return fail(SOSRT_E_INVALID, "nb_layers must be >= 2 (got %d)", L);
+    if (N < 4) return fail(SOSRT_E_INVALID, "nb_angles must be >= 4 (got %d)", N);
+    if (N > 1024) return fail(SOSRT_E_INVALID, "nb_angles must be <= 1024 (got %d)", N);
+    if (max_batch < 1 || max_orders < 1) return fail(SOSRT_E_INVALID, "max_batch and max_orders must be >= 1");
+    sosrt_handle* h = new (std::nothrow) sosrt_handle();
+    if (!h) return fail(SOSRT_E_NOMEM, "out of host memory");
+    h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;
+    h->gpu = device >= 0;
+    Grid& g = h->g;
+    g.L = L; g.N = N; g.D = 2 * N;
+    g.Dp = (g.D + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
+    g.Wld = (g.D + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
+    if (h->gpu) {
+        int e = 0;
+        auto body = [&]() -> int {
+            HIPCHK(hipSetDevice(device));
+            HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+            h->stream = h->own_stream;
+            const size_t mb = max_batch, fe = field_elems(h);
+            if ((e = dalloc(&h->d_mu, g.D))) return e;
+            if ((e = dalloc(&h->d_Wa, (size_t)g.Dp * g.Wld))) return e;
+            if ((e = dalloc(&h->d_Wr, (size_t)g.Dp * g.Wld))) return e;
+            if ((e = dalloc(&h->d_wfdn, N))) return e;
+            if ((e = dalloc(&h->d_wfup, N))) return e;
+            if ((e = dalloc(&h->d_fix, 4))) return e;
+            if ((e = dalloc(&h->d_small, N))) return e;
+            if ((e = dalloc(&h->d_idx_up, mb))) return e;
+            if ((e = dalloc(&h->d_idx_down, mb))) return e;
+            if ((e = dalloc(&h->d_scal, 7 * mb))) return e;
+            if ((e = dalloc(&h->d_desc, mb))) return e;
+            if ((e = dalloc(&h->d_rca, mb * L))) return e;
+            if ((e = dalloc(&h->d_rcr, mb * L))) return e;
+            if ((e = dalloc(&h->d_slabrows, mb * L))) return e;
+            if ((e = dalloc(&h->d_tau, mb * L))) return e;
+            if ((e = dalloc(&h->d_P0a, mb * g.D))) return e;
+            if ((e = dalloc(&h->d_P0r, mb * g.D))) return e;
+            if ((e = dalloc(&h->d_Jn, fe))) return e;
+            if ((e = dalloc(&h->d_InA, fe))) return e;
+            if ((e = dalloc(&h->d_InB, fe))) return e;
+            if ((e = dalloc(&h->d_I, fe))) return e;
+            if ((e = dalloc(&h->d_active, mb))) return e;
+            if ((e = dalloc(&h->d_norders, mb))) return e;
+            if ((e = dalloc(&h->d_status, mb))) return e;
+            if ((e = dalloc(&h->d_nactive, 1))) return e;
+            if ((e = dalloc(&h->d_ratio, mb))) return e;
+            HIPCHK(hipHostMalloc((void**)&h->h_poll, 2 * sizeof(int), hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&h->poll_ev[0], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->poll_ev[1], hipEventDisableTiming));
+            HIPCHK(hipMemset(h->d_Wa, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
+            HIPCHK(hipMemset(h->d_Wr, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
+            HIPCHK(hipMemset(h->d_status, 0, mb * sizeof(int)));
+            HIPCHK(hipMemset(h->d_tau, 0, mb * L * sizeof(double)));
+            return 0;
+        };
+        if ((e = body())) { sosrt_destroy(h); return e; }
+        g.mu = h->d_mu; g.Wa = h->d_Wa; g.Wr = h->d_Wr; g.fix = h->d_fix; g.small_lanes = h->d_small;
+        g.wflux_dn = h->d_wfdn; g.wflux_up = h->d_wfup; g.nsmall = 0;
+    }
+    *out = h;
+    return 0;
+}
+
+int sosrt_destroy(sosrt_t* h) {
+    if (!h) return 0;
+    if (h->gpu) {
+        hipSetDevice(h->device);
+        if (h->own_stream) hipStreamSynchronize(h->own_stream);
+        void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
+                        h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_tau, h->d_P0a,
+                        h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_active, h->d_norders, h->d_status,
+                        h->d_nactive, h->d_ratio};
+        for (void* p : ptrs)
+            if (p) hipFree(p);
+        if (h->h_poll) hipHostFree(h->h_poll);
+        for (auto& e : h->poll_ev)
+            if (e) hipEventDestroy(e);
+        for (auto& e : h->prof.ev) hipEventDestroy(e);
+        if (h->own_stream) hipStreamDestroy(h->own_stream);
+    }
+    delete h;
+    return 0;
+}
+
+int sosrt_set_stream(sosrt_t* h, void* s) {
+    if (int e = need_gpu(h)) return e;
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return 0;
+}
+
+int sosrt_synchronize(sosrt_t* h) {
+    if (int e = need_gpu(h)) return e;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int sosrt_set_grid(sosrt_t* h, const double* mu) {
+    if (!h || !mu) return fail(SOSRT_E_INVALID, "null argument");
+    for (int k = 0; k < h->D; ++k)
+        if (!std::isfinite(mu[k])) return fail(SOSRT_E_INVALID, "mu[%d] is not finite", k);
+    for (int k = 0; k < h->N; ++k) {
+        if (!(mu[k] <= 0)) return fail(SOSRT_E_INVALID, "mu[%d]=%g: the first nb_angles directions must be <= 0", k, mu[k]);
+        if (!(mu[h->N + k] >= 0)) return fail(SOSRT_E_INVALID, "mu[%d]=%g: the last nb_angles directions must be >= 0", h->N + k, mu[h->N + k]);
+    }
+    h->plan.set_grid(h->N, mu);
+    for (int b = 0; b < 4; ++b)
+        if (h->plan.fix[b].idx > kFixMaxIdx) return fail(SOSRT_E_INVALID, "nb_angles too large for the extrapolation tables");
+    h->have_grid = true;
+    h->have_phase = false;
+    if (h->gpu) {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpy(h->d_mu, mu, h->D * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_wfdn, h->plan.wflux_dn.data(), h->N * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_wfup, h->plan.wflux_up.data(), h->N * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<FixTab> ft(4);
+        for (int b = 0; b < 4; ++b) {
+            const FixTable& t = h->plan.fix[b];
+            memset(&ft[b], 0, sizeof(FixTab));
+            ft[b].idx = t.idx; ft[b].s0 = t.s0; ft[b].ns = t.ns;
+            for (size_t i = 0; i < t.C.size(); ++i) ft[b].C[i] = t.C[i];
+        }
+        HIPCHK(hipMemcpy(h->d_fix, ft.data(), 4 * sizeof(FixTab), hipMemcpyHostToDevice));
+        h->g.nsmall = (int)h->plan.small_lanes.size();
+        if (h->g.nsmall)
+            HIPCHK(hipMemcpy(h->d_small, h->plan.small_lanes.data(), h->g.nsmall * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer) {
+    if (!h || !P_atm) return fail(SOSRT_E_INVALID, "null argument");
+    if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
+    h->plan.fold(P_atm, h->Wa_h);
+    h->have_aer = P_aer != nullptr;
+    if (P_aer) h->plan.fold(P_aer, h->Wr_h);
+    else h->Wr_h.clear();
+    h->have_phase = true;
+    if (h->gpu) {
+        HIPCHK(hipSetDevice(h->device));
+        const Grid& g = h->g;
+        HIPCHK(hipMemcpy2D(h->d_Wa, g.Wld * sizeof(double), h->Wa_h.data(), g.D * sizeof(double), g.D * sizeof(double),
+                           g.D, hipMemcpyHostToDevice));
+        if (P_aer)
+            HIPCHK(hipMemcpy2D(h->d_Wr, g.Wld * sizeof(double), h->Wr_h.data(), g.D * sizeof(double),
+                               g.D * sizeof(double), g.D, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* idx_up, const int* idx_down,
+                      const double* mu0, const double* grd_alb, const double* alb_atm, const double* alb_aer,
+                      const double* dtau_atm, const double* dtau_aer, const double* tauStar_tot) {
+    if (int e = need_gpu(h)) return e;
+    if (B < 1 || B > h->max_batch) return fail(SOSRT_E_INVALID, "B=%d outside 1..max_batch=%d", B, h->max_batch);
+    if (!mu0 || !alb_atm || !tauStar_tot) return fail(SOSRT_E_INVALID, "mu0, alb_atm and tauStar_tot are required");
+    const size_t mb = h->max_batch;
+    std::vector<double> sc(7 * mb, 0.0);
+    std::vector<int> slab;
+    if (geometry == SOSRT_GEOM_THREE_ZONE) {
+        if (!idx_up || !idx_down || !grd_alb || !alb_aer || !dtau_atm || !dtau_aer)
+            return fail(SOSRT_E_INVALID, "three-zone geometry needs idx_up, idx_down, grd_alb, alb_aer, dtau_atm, dtau_aer");
+        if (surface != SOSRT_SURFACE_SPECULAR && surface != SOSRT_SURFACE_LAMBERTIAN)
+            return fail(SOSRT_E_INVALID, "three-zone geometry needs a specular or lambertian surface");
+        for (int b = 0; b < B; ++b) {
+            if (idx_up[b] < 1 || idx_down[b] < idx_up[b] || idx_down[b] > h->L - 2)
+                return fail(SOSRT_E_INVALID, "column %d: need 1 <= idx_up <= idx_down <= nb_layers-2 (got %d, %d)", b,
+                            idx_up[b], idx_down[b]);
+            for (int t = idx_up[b]; t <= idx_down[b]; ++t) slab.push_back(b * h->L + t);
+        }
+    } else if (geometry == SOSRT_GEOM_SINGLE_SLAB) {
+        surface = SOSRT_SURFACE_NONE;
+    } else {
+        return fail(SOSRT_E_INVALID, "unknown geometry %d", geometry);
+    }
+    for (int b = 0; b < B; ++b) {
+        if (!(mu0[b] > 0)) return fail(SOSRT_E_INVALID, "column %d: mu0 must be > 0", b);
+        sc[0 * mb + b] = mu0[b];
+        sc[1 * mb + b] = grd_alb ? grd_alb[b] : 0.0;
+        sc[2 * mb + b] = alb_atm[b];
+        sc[3 * mb + b] = alb_aer ? alb_aer[b] : 0.0;
+        sc[4 * mb + b] = dtau_atm ? dtau_atm[b] : 1.0;
+        sc[5 * mb + b] = dtau_aer ? dtau_aer[b] : 0.0;
+        sc[6 * mb + b] = tauStar_tot[b];
+    }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_scal, sc.data(), 7 * mb * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (geometry == SOSRT_GEOM_THREE_ZONE) {
+        HIPCHK(hipMemcpyAsync(h->d_idx_up, idx_up, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_idx_down, idx_down, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (!slab.empty())
+            HIPCHK(hipMemcpyAsync(h->d_slabrows, slab.data(), slab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
+    h->nslab = (int)slab.size();
+    h->B = B; h->geom = geometry; h->surface = surface;
+    h->have_cols = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// step level
+// ---------------------------------------------------------------------------------------------
+int sosrt_first_order(sosrt_t* h, int B, const double* tau, const double* P0_atm, const double* P0_aer,
+                      double* I1_out) {
+    if (int e = check_ready(h, B, false)) return e;
+    if (!tau || !P0_atm || !I1_out) return fail(SOSRT_E_INVALID, "null argument");
+    if (h->geom == SOSRT_GEOM_THREE_ZONE && !P0_aer) return fail(SOSRT_E_INVALID, "three-zone geometry needs P0_aer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)B * h->L * h->D;
+    HIPCHK(hipMemcpyAsync(h->d_tau, tau, (size_t)B * h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_P0a, P0_atm, (size_t)B * h->D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (P0_aer) HIPCHK(hipMemcpyAsync(h->d_P0r, P0_aer, (size_t)B * h->D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    launch_prepare(h->stream, h->g, B, h->geom, h->surface, scalars_of(h), h->d_tau, h->d_desc, h->d_rca, h->d_rcr);
+    prof_begin(h, SOSRT_K_FIRST);
+    launch_first_order(h->stream, h->g, B, h->d_tau, h->d_P0a, P0_aer ? h->d_P0r : nullptr, h->d_desc, h->d_InA, nullptr,
+                       nullptr, 0, make_conv(h, 0), 0);
+    prof_end(h, SOSRT_K_FIRST);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(I1_out, h->d_InA, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int sosrt_source(sosrt_t* h, int B, const double* In_1, double* Jn_out) {
+    if (int e = check_ready(h, B, true)) return e;
+    if (!In_1 || !Jn_out) return fail(SOSRT_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)B * h->L * h->D;
+    HIPCHK(hipMemcpyAsync(h->d_InA, In_1, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // the row coefficients depend on tau only through the zone bounds; prepare needs a tau buffer
+    // for the a4b buckets, which the source function does not use
+    launch_prepare(h->stream, h->g, B, h->geom, h->surface, scalars_of(h), h->d_tau, h->d_desc, h->d_rca, h->d_rcr);
+    run_source(h, h->d_InA, h->d_Jn, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(Jn_out, h->d_Jn, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, double* In_out, int* status_out) {
+    if (int e = check_ready(h, B, false)) return e;
+    if (!tau || !Jn || !In_out) return fail(SOSRT_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)B * h->L * h->D;
+    HIPCHK(hipMemcpyAsync(h->d_tau, tau, (size_t)B * h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_Jn, Jn, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    launch_prepare(h->stream, h->g, B, h->geom, h->surface, scalars_of(h), h->d_tau, h->d_desc, h->d_rca, h->d_rcr);
+    HIPCHK(hipMemsetAsync(h->d_InB, 0, n * sizeof(double), h->stream));
+    prof_begin(h, SOSRT_K_SMALLMU);
+    launch_smallmu(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, h->d_desc, nullptr);
+    prof_end(h, SOSRT_K_SMALLMU);
+    prof_begin(h, SOSRT_K_TRANSPORT);
+    launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0);
+    prof_end(h, SOSRT_K_TRANSPORT);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(In_out, h->d_InB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (status_out) HIPCHK(hipMemcpyAsync(status_out, h->d_status, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column level
+// ---------------------------------------------------------------------------------------------
+// spec:309 with In = ones when the first order is supplied by the caller
+__global__ void k_init_from_I1(Grid g, const double* __restrict__ I1, double* __restrict__ In1, double* __restrict__ I,
+                               double* __restrict__ saved, size_t saved_col_stride, Conv cv) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t n = (size_t)g.L * g.D;
+    const double* src = I1 + (size_t)b * n;
+    for (size_t i = tid; i < n; i += blockDim.x) {
+        const double v = src[i];
+        In1[(size_t)b * n + i] = v;
+        I[(size_t)b * n + i] = v;
+        if (saved) saved[(size_t)b * saved_col_stride + i] = v;
+    }
+    if (tid == 0) {
+        // the reference's test with In = ones: python max over the rows, in order
+        double a = 1.0 / src[g.N];
+        for (int m = g.N + 1; m < g.D; ++m) { const double x = 1.0 / src[m]; if (x > a) a = x; }
+        const double* last = src + (size_t)(g.L - 1) * g.D;
+        double bb = 1.0 / last[0];
+        for (int m = 1; m < g.N; ++m) { const double x = 1.0 / last[m]; if (x > bb) bb = x; }
+        const double r = (bb > a) ? bb : a;
+        cv.ratio[b] = r; cv.norders[b] = 1; cv.status[b] = SOSRT_COL_OK;
+        const int go = (r >= cv.tol) ? 1 : 0;
+        cv.active[b] = go;
+        if (go) atomicAdd(cv.nactive, 1);
+    }
+}
+
+int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_atm, const double* d_P0_aer, double tol,
+                    const double* d_I1_in, double* d_I_out, double* d_I_saved_out, int* d_n_orders_out,
+                    int* d_status_out) {
+    if (int e = check_ready(h, B, true)) return e;
+    if (!d_tau || !d_I_out) return fail(SOSRT_E_INVALID, "null argument");
+    if (!d_I1_in && !d_P0_atm) return fail(SOSRT_E_INVALID, "P0_atm is required unless I1 is supplied");
+    if (!d_I1_in && h->geom == SOSRT_GEOM_THREE_ZONE && !d_P0_aer) return fail(SOSRT_E_INVALID, "three-zone geometry needs P0_aer");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const Grid& g = h->g;
+    const size_t LD = (size_t)h->L * h->D;
+    const size_t saved_stride = (size_t)h->max_orders * LD;
+    Conv cv = make_conv(h, tol);
+
+    launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr);
+    HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
+    double* In_1 = h->d_InA;
+    double* In = h->d_InB;
+    prof_begin(h, SOSRT_K_FIRST);
+    if (d_I1_in)
+        hipLaunchKernelGGL(k_init_from_I1, dim3(B), dim3(256), 0, s, g, d_I1_in, In_1, d_I_out, d_I_saved_out, saved_stride, cv);
+    else
+        launch_first_order(s, g, B, d_tau, d_P0_atm, d_P0_aer, h->d_desc, In_1, d_I_out, d_I_saved_out, saved_stride, cv, 1);
+    prof_end(h, SOSRT_K_FIRST);
+
+    // Order loop (spec:309-458).  Converged columns are masked on the device (every kernel of an
+    // order returns at once for them).  r_k = number of live columns after order k is copied to a
+    // pinned slot after every order; before launching order k+1 the host checks r_{k-1}, which is
+    // already there while order k is still running, so the stream never drains inside the loop and
+    // at most one launch group runs on a fully converged batch.
+    int n = 1;
+    HIPCHK(hipMemcpyAsync(&h->h_poll[1], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(h->poll_ev[1], s));
+    while (n < h->max_orders) {
+        if (n >= 2) {
+            const int slot = (n - 1) & 1;
+            HIPCHK(hipEventSynchronize(h->poll_ev[slot]));
+            if (h->h_poll[slot] == 0) break;
+        }
+        ++n;
+        run_source(h, In_1, h->d_Jn, h->d_active);
+        if (g.nsmall > 0) {
+            prof_begin(h, SOSRT_K_SMALLMU);
+            launch_smallmu(s, g, B, d_tau, h->d_Jn, In, h->d_desc, h->d_active);
+            prof_end(h, SOSRT_K_SMALLMU);
+        }
+        prof_begin(h, SOSRT_K_TRANSPORT);
+        launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out,
+                         d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr, saved_stride, h->d_desc, cv, n, 1);
+        prof_end(h, SOSRT_K_TRANSPORT);
+        HIPCHK(hipMemcpyAsync(&h->h_poll[n & 1], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(h->poll_ev[n & 1], s));
+        double* tmp = In_1; In_1 = In; In = tmp;
+    }
+    launch_finalize(s, B, cv, h->max_orders);
+    HIPCHK(hipGetLastError());
+    if (d_n_orders_out) HIPCHK(hipMemcpyAsync(d_n_orders_out, h->d_norders, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (d_status_out) HIPCHK(hipMemcpyAsync(d_status_out, h->d_status, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    h->last_max_orders = n;
+    h->last_sum_orders = -1;
+    return 0;
+}
+
+int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, const double* P0_aer, double tol,
+                const double* I1_in, double* I_out, double* I_saved_out, int* n_orders_out, int* status_out) {
+    if (int e = check_ready(h, B, true)) return e;
+    if (!tau || !I_out) return fail(SOSRT_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t LD = (size_t)h->L * h->D, n = (size_t)B * LD;
+    HIPCHK(hipMemcpyAsync(h->d_tau, tau, (size_t)B * h->L * sizeof(double), hipMemcpyHostToDevice, s));
+    if (P0_atm) HIPCHK(hipMemcpyAsync(h->d_P0a, P0_atm, (size_t)B * h->D * sizeof(double), hipMemcpyHostToDevice, s));
+    if (P0_aer) HIPCHK(hipMemcpyAsync(h->d_P0r, P0_aer, (size_t)B * h->D * sizeof(double), hipMemcpyHostToDevice, s));
+    double* d_I1 = nullptr;
+    double* d_saved = nullptr;
+    int rc = 0;
+    auto body = [&]() -> int {
+        if (I1_in) {
+            if (int e = dalloc(&d_I1, n)) return e;
+            HIPCHK(hipMemcpyAsync(d_I1, I1_in, n * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        if (I_saved_out) {
+            if (int e = dalloc(&d_saved, (size_t)B * h->max_orders * LD)) return e;
+            HIPCHK(hipMemsetAsync(d_saved, 0, (size_t)B * h->max_orders * LD * sizeof(double), s));
+        }
+        if (int e = sosrt_solve_dev(h, B, h->d_tau, P0_atm ? h->d_P0a : nullptr, P0_aer ? h->d_P0r : nullptr, tol, d_I1,
+                                    h->d_I, d_saved, nullptr, nullptr))
+            return e;
+        HIPCHK(hipMemcpyAsync(I_out, h->d_I, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (I_saved_out)
+            HIPCHK(hipMemcpyAsync(I_saved_out, d_saved, (size_t)B * h->max_orders * LD * sizeof(double), hipMemcpyDeviceToHost, s));
+        std::vector<int> no(B);
+        HIPCHK(hipMemcpyAsync(no.data(), h->d_norders, B * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (status_out) HIPCHK(hipMemcpyAsync(status_out, h->d_status, B * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        long long sum = 0;
+        for (int b = 0; b < B; ++b) { sum += no[b] - 1; if (n_orders_out) n_orders_out[b] = no[b]; }
+        h->last_sum_orders = sum;
+        return 0;
+    };
+    rc = body();
+    if (d_I1) hipFree(d_I1);
+    if (d_saved) hipFree(d_saved);
+    return rc;
+}
+
+int sosrt_last_solve_stats(sosrt_t* h, int* max_orders_run, long long* sum_orders) {
+    if (int e = need_gpu(h)) return e;
+    if (h->last_sum_orders < 0 && h->B > 0) {
+        std::vector<int> no(h->B);
+        HIPCHK(hipMemcpyAsync(no.data(), h->d_norders, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        long long sum = 0;
+        for (int v : no) sum += v - 1;
+        h->last_sum_orders = sum;
+    }
+    if (max_orders_run) *max_orders_run = h->last_max_orders;
+    if (sum_orders) *sum_orders = h->last_sum_orders;
+    return 0;
+}
+
+int sosrt_fluxes(sosrt_t* h, int B, const double* tau, const double* I, int beam_norm, double* flux_down,
+                 double* flux_up) {
+    if (int e = check_ready(h, B, false)) return e;
+    if (!tau || !I || !flux_down || !flux_up) return fail(SOSRT_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t n = (size_t)B * h->L * h->D, r = (size_t)B * h->L;
+    HIPCHK(hipMemcpyAsync(h->d_tau, tau, r * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_I, I, n * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_prepare(s, h->g, B, h->geom, h->surface, scalars_of(h), h->d_tau, h->d_desc, h->d_rca, h->d_rcr);
+    launch_fluxes(s, h->g, B, h->d_tau, h->d_I, h->d_desc, beam_norm, h->d_rca, h->d_rcr);   // row-sized scratch
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(flux_down, h->d_rca, r * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(flux_up, h->d_rcr, r * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int sosrt_limit_mu_down(sosrt_t* h, int R, int idx, const double* rows, double* out) {
+    if (int e = need_gpu(h)) return e;
+    if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
+    if (R < 1 || !rows || !out) return fail(SOSRT_E_INVALID, "bad argument");
+    int table = -1;
+    for (int b = 0; b < 4; ++b)
+        if (h->plan.fix[b].idx == idx) table = b;
+    if (table < 0) return fail(SOSRT_E_INVALID, "idx=%d is not one of the reference's int(c*nb_angles) values for nb_angles=%d", idx, h->N);
+    if (idx == 0) return 0;
+    if ((size_t)R * h->N > field_elems(h)) return fail(SOSRT_E_INVALID, "too many rows");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_Jn, rows, (size_t)R * h->N * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_limit_rows(s, h->g, R, table, h->d_Jn, h->d_InB);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->d_InB, (size_t)R * idx * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int sosrt_asymptotic_down(sosrt_t* h, int R, int stride, const int* len, const double* J, const double* tau,
+                          const double* tau_t, const double* mu, double* out) {
+    if (int e = need_gpu(h)) return e;
+    if (R < 1 || stride < 1 || !len || !J || !tau || !tau_t || !mu || !out) return fail(SOSRT_E_INVALID, "bad argument");
+    const size_t n = (size_t)R * stride;
+    if (2 * n + 4 * (size_t)R > field_elems(h)) return fail(SOSRT_E_INVALID, "too many rows");
+    for (int r = 0; r < R; ++r)
+        if (len[r] < 0 || len[r] > stride) return fail(SOSRT_E_INVALID, "len[%d] out of range", r);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    double* dJ = h->d_Jn; double* dT = h->d_Jn + n;
+    double* dtt = h->d_InB; double* dmu = h->d_InB + R; double* dout = h->d_InB + 2 * (size_t)R;
+    int* dlen = (int*)(h->d_InA);
+    HIPCHK(hipMemcpyAsync(dJ, J, n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dT, tau, n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dtt, tau_t, R * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dmu, mu, R * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dlen, len, R * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_asymptotic(s, R, stride, dlen, dJ, dT, dtt, dmu, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout, R * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan introspection (host only)
+// ---------------------------------------------------------------------------------------------
+int sosrt_plan_weights(sosrt_t* h, double* w_out) {
+    if (!h || !w_out) return fail(SOSRT_E_INVALID, "null argument");
+    if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
+    memcpy(w_out, h->plan.w.data(), h->D * sizeof(double));
+    return 0;
+}
+
+int sosrt_plan_fold(sosrt_t* h, int which, double* W_out) {
+    if (!h || !W_out) return fail(SOSRT_E_INVALID, "null argument");
+    if (!h->have_phase) return fail(SOSRT_E_STATE, "sosrt_set_phase has not been called");
+    const std::vector<double>& W = which ? h->Wr_h : h->Wa_h;
+    if (W.empty()) return fail(SOSRT_E_STATE, "that phase matrix was not set");
+    memcpy(W_out, W.data(), W.size() * sizeof(double));
+    return 0;
+}
+
+int sosrt_plan_fix_table(sosrt_t* h, int idx, int* s0, int* ns, double* C_out) {
+    if (!h || !s0 || !ns) return fail(SOSRT_E_INVALID, "null argument");
+    if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
+    if (idx < 0 || idx > kFixMaxIdx || idx + 5 > h->N) return fail(SOSRT_E_INVALID, "idx out of range");
+    FixTable t = h->plan.make_fix_table(idx);
+    *s0 = t.s0; *ns = t.ns;
+    if (C_out && !t.C.empty()) memcpy(C_out, t.C.data(), t.C.size() * sizeof(double));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------------------------
+int sosrt_profile_enable(sosrt_t* h, int on) {
+    if (int e = need_gpu(h)) return e;
+    Prof& p = h->prof;
+    if (on && p.ev.empty()) {
+        HIPCHK(hipSetDevice(h->device));
+        p.ev.resize(2 * kProfPool);
+        p.kind.assign(kProfPool, -1);
+        for (auto& e : p.ev) HIPCHK(hipEventCreate(&e));
+    }
+    p.on = on != 0;
+    return 0;
+}
+
+int sosrt_profile_reset(sosrt_t* h) {
+    if (int e = need_gpu(h)) return e;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prof.used = 0;
+    return 0;
+}
+
+int sosrt_profile_get(sosrt_t* h, int kernel, double* total_ms, long long* launches, double* work) {
+    if (int e = need_gpu(h)) return e;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double tot = 0;
+    long long cnt = 0;
+    Prof& p = h->prof;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        if (p.kind[i / 2] != kernel) continue;
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        tot += ms;
+        ++cnt;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = cnt;
+    if (work) *work = 0;
+    return 0;
+}
+
+}  // extern "C"

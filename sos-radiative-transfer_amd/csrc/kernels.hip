@@ -1,0 +1,788 @@
+// HIP kernels of the SOS hot path for gfx950 (CDNA4, wave64).
+//
+//   k_prepare      per-column zone table + Jn row coefficients            (spec:40-53, 342-345)
+//   k_first_order  closed-form first order I1, three-zone or single slab  (spec:104-292, I1_In:13-58)
+//   k_jn_gemm      Jn = diag(c) In_1 W   as an FP64-MFMA contraction        (spec:314-323, I1_In:62-74)
+//   k_smallmu      windowed / Taylor value of the |mu| < 0.01 lanes        (In_limit:70-109)
+//   k_transport    per-order layer recurrences, mu->0 treatments, surface,
+//                  accumulation and the convergence test                   (spec:326-458, I1_In:77-130)
+//   k_fluxes       flux epilogue                                           (graphe:157-158, crit:377-382)
+//
+// Layout: every radiance field is [column][layer t][direction m], m fastest, so that one
+// wavefront reads 64 consecutive directions of one layer (512 B, coalesced).
+#include "kernels.hpp"
+
+#include "../../include/sosrt.h"
+
+namespace sosrt {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+#define SOSRT_PI 3.14159265358979323846
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_fmax(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));   // fmax drops NaN operands
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Python's builtin max() over x[0..n) as the reference's loop test applies it to a NumPy row
+// (spec:309): the first element seeds the running maximum and NaN never wins a comparison, so
+// the result is NaN iff x[0] is NaN, else the largest non-NaN element.  `x` is this thread's
+// element (thread i holds x[i]), `valid` marks i < n.  Every thread gets the result.
+__device__ double block_pymax(double x, bool valid, double* s_red) {
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    double v = wave_fmax(valid ? x : __builtin_nan(""));
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    if (tid == 0) s_red[nw] = x;
+    __syncthreads();
+    double r = s_red[0];
+    for (int i = 1; i < nw; ++i) r = fmax(r, s_red[i]);
+    const double first = s_red[nw];
+    return (first != first) ? first : r;
+}
+
+__device__ double block_sum(double x, double* s_red) {
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    double v = wave_sum(x);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    for (int i = 0; i < nw; ++i) r += s_red[i];
+    return r;
+}
+
+// the loop test of spec:309 given max-over-row results a (TOA, upward) and b (surface, downward)
+__device__ __forceinline__ double outer_pymax(double a, double b) { return (b > a) ? b : a; }
+
+__device__ __forceinline__ int d_fix_bucket(double tau_ref) {
+    if (tau_ref <= 0.0625) return 0;
+    if (tau_ref <= 1) return 1;
+    if (tau_ref < 4) return 2;
+    return 3;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_prepare: zone table per column
+// ------------------------------------------------------------------------------------------
+__global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, const double* __restrict__ tau,
+                          ColDesc* __restrict__ desc, double* __restrict__ rowcoef_a,
+                          double* __restrict__ rowcoef_r) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    __shared__ ColDesc d;
+    const double* tb = tau + (size_t)b * g.L;
+    if (threadIdx.x == 0) {
+        const int L = g.L;
+        d.surface = surface;
+        d.geom = geom;
+        d.mu0 = sc.mu0[b];
+        d.T = sc.T[b];
+        d.wa = sc.alb_atm[b];
+        double tref[kMaxZones];
+        if (geom == SOSRT_GEOM_THREE_ZONE) {
+            const int iu = sc.idx_up[b], id = sc.idx_down[b];
+            d.nz = 3;
+            d.r0[0] = 0;      d.r1[0] = iu - 1; d.mix[0] = 0;
+            d.r0[1] = iu;     d.r1[1] = id;     d.mix[1] = 1;
+            d.r0[2] = id + 1; d.r1[2] = L - 1;  d.mix[2] = 0;
+            tref[0] = tb[iu - 1]; tref[1] = tb[id]; tref[2] = tb[id];   // spec:342,361,380
+            d.rho = sc.rho[b];
+            d.wr = sc.alb_aer[b];
+            const double da = sc.dtau_atm[b], dr = sc.dtau_aer[b];
+            d.fa = da / (da + dr);
+            d.fr = dr / (da + dr);
+            d.tau_bottom = tb[L - 1];
+            d.ca[0] = d.wa / 4; d.cr[0] = 0;
+            d.ca[1] = (d.wa / 4) * d.fa; d.cr[1] = (d.wr / 4) * d.fr;  // spec:321
+            d.ca[2] = d.wa / 4; d.cr[2] = 0;
+        } else {
+            d.nz = 1;
+            d.r0[0] = 0; d.r1[0] = L - 1; d.mix[0] = 0;
+            for (int z = 1; z < kMaxZones; ++z) { d.r0[z] = L; d.r1[z] = L - 1; d.mix[z] = 0; d.ca[z] = 0; d.cr[z] = 0; tref[z] = 0; }
+            tref[0] = d.T;                                               // I1_In:124 uses tauStar
+            d.rho = 0; d.wr = 0; d.fa = 1; d.fr = 0;
+            d.tau_bottom = d.T;                                          // I1_In:54 uses tauStar, not tau[-1]
+            d.ca[0] = d.wa / 4; d.cr[0] = 0;
+        }
+        for (int z = 0; z < kMaxZones; ++z) {
+            const int k = d_fix_bucket(tref[z]);
+            d.fixtab[z] = k;
+            d.nfix[z] = (z < d.nz) ? g.fix[k].idx : 0;
+        }
+        desc[b] = d;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.L; t += blockDim.x) {
+        int z = 0;
+        while (z + 1 < d.nz && t > d.r1[z]) ++z;
+        rowcoef_a[(size_t)b * g.L + t] = d.ca[z];
+        rowcoef_r[(size_t)b * g.L + t] = d.cr[z];
+    }
+}
+
+void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
+                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r) {
+    hipLaunchKernelGGL(k_prepare, dim3(B), dim3(128), 0, s, g, B, geom, surface, sc, tau, desc, rowcoef_a, rowcoef_r);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_first_order
+// One workgroup per column, thread j owns the downward direction m = j and then the upward
+// direction m = N + j; the layer loop is sequential only because each zone starts from the
+// attenuated last row of the previous one ("scatt_before", spec:147,176,240,270).
+// ------------------------------------------------------------------------------------------
+__global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const double* __restrict__ P0a_all,
+                              const double* __restrict__ P0r_all, const ColDesc* __restrict__ desc,
+                              double* __restrict__ I1_all, double* __restrict__ I_all, double* __restrict__ saved,
+                              size_t saved_col_stride, Conv cv, int do_conv) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int L = g.L, N = g.N, D = g.D;
+    extern __shared__ double sm[];
+    double* s_tau = sm;                 // [L]
+    double* s_sfc = s_tau + L;          // [blockDim]
+    double* s_red = s_sfc + blockDim.x; // [nw + 1]
+    __shared__ ColDesc d;                // dynamically indexed: keep it out of scratch
+    if (tid == 0) d = desc[b];
+    const double* tau = tau_all + (size_t)b * L;
+    const double* P0a = P0a_all + (size_t)b * D;
+    const double* P0r = P0r_all ? P0r_all + (size_t)b * D : P0a;
+    double* I1 = I1_all + (size_t)b * L * D;
+    double* Iacc = I_all ? I_all + (size_t)b * L * D : nullptr;
+    double* sv = saved ? saved + (size_t)b * saved_col_stride : nullptr;
+    for (int t = tid; t < L; t += blockDim.x) s_tau[t] = tau[t];
+    __syncthreads();
+
+    const double mu0 = d.mu0, T = d.T, rho = d.rho;
+    const double F0 = SOSRT_PI / mu0;                       // spec:105
+    const double R = F0 * rho * exp(-T / mu0);              // reflected beam at the surface
+    const double c4pi = 1.0 / (4 * SOSRT_PI);
+    const bool valid = tid < N;
+    double rdn = 0, rup = 0;                                // ratios of the first loop test (In = ones)
+
+    // ---- downward, m = tid ----
+    {
+        const int m = tid;
+        const int mm = valid ? m : 0, mir = 2 * N - 1 - mm;
+        const double mu = g.mu[mm];
+        const double qa = d.wa * P0a[mm] * c4pi, qam = d.wa * P0a[mir] * c4pi;
+        const double qx = (d.wa * P0a[mm] * d.fa + d.wr * P0r[mm] * d.fr) * c4pi;
+        const double qxm = (d.wa * P0a[mir] * d.fa + d.wr * P0r[mir] * d.fr) * c4pi;
+        const bool near = fabs(mu + mu0) < 0.0001;          // spec:111
+        double Ib = 0, v = 0;
+        for (int z = 0; z < d.nz; ++z) {
+            const double q = d.mix[z] ? qx : qa, qm = d.mix[z] ? qxm : qam;
+            const double t_bd = z ? s_tau[d.r0[z] - 1] : 0.0;
+            const double t_bs = z ? s_tau[d.r0[z]] : 0.0;
+            const double e_bd = exp(-t_bd / mu0), e_bs = exp(-(T - t_bs) / mu0);
+            for (int t = d.r0[z]; t <= d.r1[z]; ++t) {
+                const double tt = s_tau[t];
+                const double e0 = exp(-tt / mu0), eT = exp(-(T - tt) / mu0);
+                if (m <= N - 2) {
+                    const double x = exp((tt - t_bd) / mu);
+                    const double before = z ? Ib * x : 0.0;
+                    const double direct = near ? q * F0 * e0 * (tt - t_bd) / mu0
+                                               : (mu0 / (mu0 + mu)) * q * F0 * (e0 - e_bd * x);
+                    const double surf = (mu0 / (mu0 - mu)) * qm * R * (eT - e_bs * exp((tt - t_bs) / mu));
+                    v = before + direct + surf;
+                } else {                                     // the mu = 0- node (spec:128-131)
+                    v = (mu0 / (mu0 + mu)) * q * F0 * e0 + (mu0 / (mu0 - mu)) * qm * R * eT;
+                }
+                if (valid) {
+                    I1[(size_t)t * D + m] = v;
+                    if (Iacc) Iacc[(size_t)t * D + m] = v;
+                    if (sv) sv[(size_t)t * D + m] = v;
+                }
+            }
+            Ib = v;
+        }
+        s_sfc[tid] = v;                                       // I1[L-1][m]
+        rdn = 1.0 / v;
+    }
+    __syncthreads();
+    // ---- upward, m = N + tid, zones bottom to top ----
+    {
+        const int j = valid ? tid : 0, m = N + j, mir = N - 1 - j;
+        const double mu = g.mu[m];
+        const double qa = d.wa * P0a[m] * c4pi, qam = d.wa * P0a[mir] * c4pi;
+        const double qx = (d.wa * P0a[m] * d.fa + d.wr * P0r[m] * d.fr) * c4pi;
+        const double qxm = (d.wa * P0a[mir] * d.fa + d.wr * P0r[mir] * d.fr) * c4pi;
+        const bool near = fabs(mu - mu0) < 0.0001;           // spec:204
+        double Bv = rho * s_sfc[mir];                          // spec:211
+        double v = 0;
+        for (int z = d.nz - 1; z >= 0; --z) {
+            const bool bottom = z == d.nz - 1;
+            const double q = d.mix[z] ? qx : qa, qm = d.mix[z] ? qxm : qam;
+            const double t_bu = bottom ? d.tau_bottom : s_tau[d.r1[z] + 1];
+            const double t_bb = bottom ? s_tau[L - 1] : t_bu;
+            const double t_su = bottom ? T : s_tau[d.r1[z]];
+            const double e_bu = exp(-t_bu / mu0), e_su = exp(-(T - t_su) / mu0);
+            for (int t = d.r1[z]; t >= d.r0[z]; --t) {
+                const double tt = s_tau[t];
+                const double e0 = exp(-tt / mu0), eT = exp(-(T - tt) / mu0);
+                if (j >= 1) {
+                    const double before = Bv * exp(-(t_bb - tt) / mu);
+                    const double direct = (mu0 / (mu0 + mu)) * q * F0 * (e0 - e_bu * exp(-(t_bu - tt) / mu));
+                    const double surf = near ? qm * R * eT * (t_su - tt) / mu0
+                                             : (mu0 / (mu0 - mu)) * qm * R * (eT - e_su * exp(-(t_su - tt) / mu));
+                    v = before + direct + surf;
+                } else {                                     // the mu = 0+ node (spec:221-224)
+                    v = (mu0 / (mu0 + mu)) * q * F0 * e0 + (mu0 / (mu0 - mu)) * qm * R * eT;
+                }
+                if (valid) {
+                    I1[(size_t)t * D + m] = v;
+                    if (Iacc) Iacc[(size_t)t * D + m] = v;
+                    if (sv) sv[(size_t)t * D + m] = v;
+                }
+            }
+            Bv = v;                                           // row r0 of this zone feeds the zone above
+        }
+        rup = 1.0 / v;                                        // v = I1[0][m]
+    }
+    if (do_conv) {
+        const double a = block_pymax(rup, valid, s_red);
+        const double bb = block_pymax(rdn, valid, s_red);
+        const double r = outer_pymax(a, bb);
+        if (tid == 0) {
+            cv.ratio[b] = r;
+            cv.norders[b] = 1;
+            cv.status[b] = SOSRT_COL_OK;
+            const int go = (r >= cv.tol) ? 1 : 0;
+            cv.active[b] = go;
+            if (go) atomicAdd(cv.nactive, 1);
+        }
+    }
+}
+
+static int round64(int n) { return (n + 63) / 64 * 64; }
+
+void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, const double* P0a, const double* P0r,
+                        const ColDesc* desc, double* I1_out, double* I_out, double* saved, size_t saved_col_stride,
+                        Conv cv, int do_conv) {
+    const int nt = round64(g.N);
+    const size_t shm = (size_t)(g.L + nt + nt / 64 + 2) * sizeof(double);
+    hipLaunchKernelGGL(k_first_order, dim3(B), dim3(nt), shm, s, g, tau, P0a, P0r, desc, I1_out, I_out, saved,
+                       saved_col_stride, cv, do_conv);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_jn_gemm:  C[r][:] (+)= coef[r] * (A[r][:] @ W)      rows r = layers of all columns
+//
+// FP64 MFMA (v_mfma_f64_16x16x4_f64): lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; the 4 results of lane l are D[i = 4r + (l>>4)][j = l&15], r = 0..3.
+// Workgroup tile 64 rows x 128 columns, 4 waves, each wave 4x2 MFMA tiles; operands staged
+// through LDS in k-chunks of 16 with row strides chosen so that ds_read_b64 is conflict-free
+// (A: stride 18 doubles = 36 dwords, 36/4 odd; B: stride 144 doubles = 288 = 32 mod 64 dwords).
+// ------------------------------------------------------------------------------------------
+constexpr int A_LD = GEMM_KC + 2;
+constexpr int B_LD = GEMM_BN + 16;
+
+__global__ __launch_bounds__(256) void k_jn_gemm(const double* __restrict__ A, const double* __restrict__ W,
+                                                 const double* __restrict__ coef, const int* __restrict__ rowlist,
+                                                 int nrows, int D, int Dp, int Wld, int L,
+                                                 double* __restrict__ C, int accumulate,
+                                                 const int* __restrict__ active) {
+    __shared__ double sA[GEMM_BM * A_LD];
+    __shared__ double sB[GEMM_KC * B_LD];
+    __shared__ int s_any;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = blockIdx.x * GEMM_BM, bn0 = blockIdx.y * GEMM_BN;
+
+    // rows of this tile; skip the tile when every column it touches has converged
+    const int arow = tid >> 2, akq = (tid & 3) * 4;
+    int grow = -1;
+    if (bm0 + arow < nrows) grow = rowlist ? rowlist[bm0 + arow] : bm0 + arow;
+    if (active) {
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        if ((tid & 3) == 0 && grow >= 0 && active[grow / L]) s_any = 1;
+        __syncthreads();
+        if (!s_any) return;
+    }
+
+    f64x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+
+    const int bk = tid >> 4, bc = (tid & 15) * 8;
+    const double* Arow = grow >= 0 ? A + (size_t)grow * D : A;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    for (int kc = 0; kc < Dp; kc += GEMM_KC) {
+        // global -> registers
+        double2 a01 = make_double2(0, 0), a23 = make_double2(0, 0);
+        const int k0 = kc + akq;
+        if (grow >= 0) {
+            if (k0 + 1 < D) a01 = *reinterpret_cast<const double2*>(Arow + k0);
+            if (k0 + 3 < D) a23 = *reinterpret_cast<const double2*>(Arow + k0 + 2);
+        }
+        const double* Wp = W + (size_t)(kc + bk) * Wld + bn0 + bc;
+        const double2 b0 = *reinterpret_cast<const double2*>(Wp);
+        const double2 b1 = *reinterpret_cast<const double2*>(Wp + 2);
+        const double2 b2 = *reinterpret_cast<const double2*>(Wp + 4);
+        const double2 b3 = *reinterpret_cast<const double2*>(Wp + 6);
+        __syncthreads();   // previous chunk consumed
+        *reinterpret_cast<double2*>(&sA[arow * A_LD + akq]) = a01;
+        *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2]) = a23;
+        double* sb = &sB[bk * B_LD + bc];
+        *reinterpret_cast<double2*>(sb) = b0;
+        *reinterpret_cast<double2*>(sb + 2) = b1;
+        *reinterpret_cast<double2*>(sb + 4) = b2;
+        *reinterpret_cast<double2*>(sb + 6) = b3;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KC; kk += 4) {
+            double af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = sA[(i * 16 + fr) * A_LD + kk + fk];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = sB[(kk + fk) * B_LD + wave * 32 + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: lane holds column (l & 15), rows 4r + (l >> 4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lr = bm0 + i * 16 + 4 * r + fk;
+            if (lr >= nrows) continue;
+            const int gr = rowlist ? rowlist[lr] : lr;
+            const double cf = coef[gr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = bn0 + wave * 32 + j * 16 + fr;
+                if (col < D) {
+                    double* p = C + (size_t)gr * D + col;
+                    const double v = cf * acc[i][j][r];
+                    *p = accumulate ? (*p + v) : v;
+                }
+            }
+        }
+    }
+}
+
+void launch_gemm(hipStream_t s, const Grid& g, const double* A, const double* W, const double* coef,
+                 const int* rowlist, int nrows, double* C, int accumulate, const int* active) {
+    if (nrows <= 0) return;
+    dim3 grid((nrows + GEMM_BM - 1) / GEMM_BM, (g.D + GEMM_BN - 1) / GEMM_BN);
+    hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), 0, s, A, W, coef, rowlist, nrows, g.D, g.Dp, g.Wld, g.L, C,
+                       accumulate, active);
+}
+
+// ------------------------------------------------------------------------------------------
+// improved_asymptotic_downward_radiance (In_limit:70-109) for one (layer, lane): the slice is
+// zone-local [zs, t] (spec:334,353,372).
+// ------------------------------------------------------------------------------------------
+__device__ double small_mu_value(const double* __restrict__ J, size_t jstride, const double* __restrict__ tau, int zs,
+                                 int t, double mu) {
+    const double Jt = J[(size_t)t * jstride];
+    if (fabs(mu) < kMuVerySmall) {                            // both Taylor branches (In_limit:79-93)
+        double slope = 0.0;
+        if (t > zs) slope = (Jt - J[(size_t)(t - 1) * jstride]) / (tau[t] - tau[t - 1]);
+        return -Jt + mu * slope;
+    }
+    const double tt = tau[t];
+    const double lim = tt - 5 * fabs(mu);                     // In_limit:97-98
+    if (!(tt >= lim)) return -Jt;                             // empty window
+    double acc = 0, fprev = Jt * exp((tt - tt) / mu);
+    bool bad = !isfinite(fprev);
+    for (int s = t - 1; s >= zs && tau[s] >= lim; --s) {
+        const double f = J[(size_t)s * jstride] * exp((tt - tau[s]) / mu);
+        bad = bad || !isfinite(f);
+        acc += (tau[s + 1] - tau[s]) * (fprev + f) / 2;
+        fprev = f;
+    }
+    if (bad) return -Jt;                                      // In_limit:104-105
+    return -acc / mu;
+}
+
+__global__ void k_smallmu(Grid g, const double* __restrict__ tau_all, const double* __restrict__ Jn_all,
+                          double* __restrict__ In_all, const ColDesc* __restrict__ desc,
+                          const int* __restrict__ active) {
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.L) return;
+    const int m = g.small_lanes[blockIdx.y];
+    const ColDesc& d = desc[b];
+    int z = 0;
+    while (z + 1 < d.nz && t > d.r1[z]) ++z;
+    if (m >= g.N - d.nfix[z]) return;                        // rewritten by the extrapolation anyway
+    const double* tau = tau_all + (size_t)b * g.L;
+    const double* J = Jn_all + (size_t)b * g.L * g.D + m;
+    In_all[((size_t)b * g.L + t) * g.D + m] = small_mu_value(J, g.D, tau, d.r0[z], t, g.mu[m]);
+}
+
+void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
+                    const ColDesc* desc, const int* active) {
+    if (g.nsmall <= 0) return;
+    dim3 grid((g.L + 63) / 64, g.nsmall, B);
+    hipLaunchKernelGGL(k_smallmu, grid, dim3(64), 0, s, g, tau, Jn, In, desc, active);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_transport: one order of transport for one column per workgroup.
+//
+// Thread j carries the downward direction m = j through the layers top to bottom as the
+// first-order recurrence
+//     D_t = E D_{t-1} - (dl/2) (J_{t-1} E + J_t) / mu ,   E = exp(dl / mu),  dl = tau_t - tau_{t-1}
+// which is the reference's trapezoid sum  -trapz(J exp((tau_t - tau)/mu), tau) / mu  (spec:336-340)
+// evaluated incrementally, then the upward direction m = N + j bottom to top as
+//     U_t = E U_{t+1} + (dl/2) (J_t + J_{t+1} E) / mu ,   E = exp(-dl / mu), dl = tau_{t+1} - tau_t
+// (spec:393-399), with the reference's zone restarts: the upward quadrature skips the interval
+// under each zone (spec:413,433) and restarts from the already blended boundary row
+// (SURVEY H5).  Rows are exchanged through LDS for the two mu -> 0 treatments that couple
+// directions: the extrapolation of the last downward angles (In_limit:113-141, here a fixed
+// linear map) and the upward second-difference search and blend (spec:402-409).
+// ------------------------------------------------------------------------------------------
+constexpr int TU = 4;   // rows loaded ahead of the recurrence
+
+struct TransportArgs {
+    Grid g;
+    const double* tau;
+    const double* Jn;
+    double* In;
+    double* I;
+    double* saved;
+    size_t saved_col_stride;
+    const ColDesc* desc;
+    Conv cv;
+    int order;
+    int accumulate;
+};
+
+__global__ void k_transport(TransportArgs a) {
+    const int b = blockIdx.x;
+    if (a.accumulate && !a.cv.active[b]) return;
+    const Grid& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int L = g.L, N = g.N, D = g.D;
+    const int SR = blockDim.x + 2;
+    extern __shared__ double sm[];
+    double* s_tau = sm;                      // [L]
+    double* s_row = s_tau + L;               // [2][SR]
+    double* s_sfc = s_row + 2 * SR;          // [blockDim]
+    double* s_red = s_sfc + blockDim.x;      // [nw + 1]
+    __shared__ ColDesc d;                    // dynamically indexed: keep it out of scratch
+    if (tid == 0) d = a.desc[b];
+    const double* tau = a.tau + (size_t)b * L;
+    const double* J = a.Jn + (size_t)b * L * D;
+    double* In = a.In + (size_t)b * L * D;
+    double* Iacc = a.accumulate ? a.I + (size_t)b * L * D : nullptr;
+    double* sv = a.saved ? a.saved + (size_t)b * a.saved_col_stride : nullptr;
+    for (int t = tid; t < L; t += blockDim.x) s_tau[t] = tau[t];
+    if (tid < 2) { s_row[blockDim.x + tid] = 0; s_row[SR + blockDim.x + tid] = 0; }
+    __syncthreads();
+
+    const bool valid = tid < N;
+    double rdn = 0, rup = 0;
+    int p = 0;
+
+    // =============================== downward ===============================
+    {
+        const int m = tid;
+        const double mu = valid ? g.mu[m] : -1.0;
+        const bool tr = valid && m <= N - 2;
+        const bool small = tr && fabs(mu) < kMuThreshold;       // spec:333
+        const bool stdl = tr && !small;
+        double Dv = 0, Jprev = 0;
+        int z = 0, nfx = d.nfix[0], s0 = 0, ns = 0;
+        double c[kFixMaxSrc] = {0, 0, 0, 0, 0};
+        bool fixlane = false;
+        auto load_fix = [&](int zz) {
+            nfx = d.nfix[zz];
+            const FixTab& ft = g.fix[d.fixtab[zz]];
+            s0 = ft.s0; ns = ft.ns;
+            fixlane = valid && nfx > 0 && m >= N - nfx;
+            if (fixlane) {
+                const int i = N - 1 - m;
+#pragma unroll
+                for (int q = 0; q < kFixMaxSrc; ++q) c[q] = q < ns ? ft.C[i * ns + q] : 0.0;
+            }
+        };
+        load_fix(0);
+        for (int t0 = 0; t0 < L; t0 += TU) {
+            double Jr[TU], Ir[TU], Sr[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int t = t0 + u;
+                const bool ok = valid && t < L;
+                Jr[u] = ok ? J[(size_t)t * D + m] : 0.0;
+                Ir[u] = (ok && Iacc) ? Iacc[(size_t)t * D + m] : 0.0;
+                Sr[u] = (ok && small) ? In[(size_t)t * D + m] : 0.0;   // written by k_smallmu
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int t = t0 + u;
+                if (t >= L) break;
+                if (t > d.r1[z]) { ++z; load_fix(z); }
+                const double Jt = Jr[u];
+                if (stdl && t > 0) {
+                    const double dl = s_tau[t] - s_tau[t - 1];
+                    const double E = exp(dl / mu);
+                    Dv = Dv * E - (dl / 2) * (Jprev * E + Jt) / mu;
+                }
+                double v = stdl ? Dv : (small ? Sr[u] : 0.0);
+                if (nfx > 0) {                                      // block-uniform
+                    if (valid) s_row[p * SR + m] = v;
+                    __syncthreads();
+                    if (fixlane) {
+                        double acc = 0;
+#pragma unroll
+                        for (int q = 0; q < kFixMaxSrc; ++q)
+                            if (q < ns) acc += c[q] * s_row[p * SR + s0 + q];
+                        v = acc;
+                    }
+                    p ^= 1;
+                }
+                double Inew = 0;
+                if (valid) {
+                    In[(size_t)t * D + m] = v;
+                    if (Iacc) { Inew = Ir[u] + v; Iacc[(size_t)t * D + m] = Inew; }
+                    if (sv) sv[(size_t)t * D + m] = v;
+                }
+                if (t == L - 1) { s_sfc[tid] = v; rdn = v / Inew; }
+                if (t == d.r1[z]) Dv = v;                           // the next zone starts from the final row (spec:359,378)
+                Jprev = Jt;
+            }
+        }
+    }
+    __syncthreads();
+
+    // =============================== surface ===============================
+    double Bv = 0;
+    if (d.surface == SOSRT_SURFACE_SPECULAR) {
+        Bv = valid ? d.rho * s_sfc[N - 1 - tid] : 0.0;              // spec:397
+    } else if (d.surface == SOSRT_SURFACE_LAMBERTIAN) {
+        // -2 rho trapz(In[L-1, rev] mu[rev], mu[rev]), rev = N-2 .. 0   (lam:399), descending abscissae
+        double term = 0;
+        if (tid <= N - 3) {
+            const int k0 = N - 2 - tid, k1 = k0 - 1;
+            const double x0 = g.mu[k0], x1 = g.mu[k1];
+            term = (x1 - x0) * (s_sfc[k1] * x1 + s_sfc[k0] * x0) / 2;
+        }
+        const double S = block_sum(term, s_red);
+        Bv = -2 * d.rho * S;
+    }
+
+    // =============================== upward ===============================
+    int status = SOSRT_COL_OK;
+    {
+        const int j = tid;
+        const double mu = (valid && j > 0) ? g.mu[N + j] : 1.0;
+        const bool tr = valid && j > 0;
+        double U = Bv, Jnext = 0;
+        int z = d.nz - 1;
+        for (int t0 = L - 1; t0 >= 0; t0 -= TU) {
+            double Jr[TU], Ir[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int t = t0 - u;
+                const bool ok = valid && t >= 0;
+                Jr[u] = ok ? J[(size_t)t * D + N + j] : 0.0;
+                Ir[u] = (ok && Iacc) ? Iacc[(size_t)t * D + N + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int t = t0 - u;
+                if (t < 0) break;
+                if (t < d.r0[z]) --z;
+                const double Jt = Jr[u];
+                if (tr && t < L - 1) {
+                    const double dl = s_tau[t + 1] - s_tau[t];
+                    const double E = exp(-dl / mu);
+                    if (t == d.r1[z]) U = U * E;                    // first row of a zone: attenuate only (spec:413-419,433-439)
+                    else U = U * E + (dl / 2) * (Jt + Jnext * E) / mu;
+                }
+                const double r = (j == 0) ? Jt : U;                 // spec:401
+                if (valid) s_row[p * SR + j] = r;
+                __syncthreads();
+                // second-difference search from the first upward angle (spec:403-406)
+                const double* row = s_row + p * SR;
+                int ks = -1;
+                {
+                    const int jj = lane;
+                    bool stop = false;
+                    if (jj >= 1 && jj <= N - 3) {
+                        const double x0 = row[jj], x1 = row[jj + 1], x2 = row[jj + 2];
+                        stop = !(fabs((x0 - x1) - (x1 - x2)) > 0.0001);
+                    }
+                    const unsigned long long mk = __ballot(stop);
+                    if (mk) ks = __ffsll((long long)mk) - 1;
+                    else {
+                        for (int q = 64; q <= N - 3; ++q) {
+                            const double x0 = row[q], x1 = row[q + 1], x2 = row[q + 2];
+                            if (!(fabs((x0 - x1) - (x1 - x2)) > 0.0001)) { ks = q; break; }
+                        }
+                    }
+                }
+                if (ks < 0) { status = SOSRT_COL_INDEXERROR; break; }    // the reference raises IndexError here
+                const int kf = ks + 1;
+                double v = r;
+                if (tr && j < kf) {
+                    const double w = mu / g.mu[N + kf];
+                    v = (1 - w) * row[0] + w * row[kf];                 // spec:407-409
+                }
+                p ^= 1;
+                double Inew = 0;
+                if (valid) {
+                    In[(size_t)t * D + N + j] = v;
+                    if (Iacc) { Inew = Ir[u] + v; Iacc[(size_t)t * D + N + j] = Inew; }
+                    if (sv) sv[(size_t)t * D + N + j] = v;
+                }
+                if (t == 0) rup = v / Inew;
+                if (t == d.r0[z] && z > 0 && tr) U = v;                 // blended row feeds the zone above
+                Jnext = Jt;
+            }
+            if (status != SOSRT_COL_OK) break;
+        }
+    }
+    if (status != SOSRT_COL_OK) {
+        if (tid == 0) {
+            a.cv.status[b] = status;
+            if (a.accumulate) {
+                a.cv.active[b] = 0;
+                a.cv.norders[b] = a.order;
+                atomicSub(a.cv.nactive, 1);
+            }
+        }
+        return;
+    }
+    if (a.accumulate) {
+        const double ra = block_pymax(rup, valid, s_red);
+        const double rb = block_pymax(rdn, valid, s_red);
+        const double r = outer_pymax(ra, rb);
+        if (tid == 0) {
+            a.cv.ratio[b] = r;
+            a.cv.norders[b] = a.order;
+            if (!(r >= a.cv.tol)) {
+                a.cv.active[b] = 0;
+                atomicSub(a.cv.nactive, 1);
+            }
+        }
+    } else if (tid == 0 && a.cv.status) {
+        a.cv.status[b] = SOSRT_COL_OK;
+    }
+}
+
+void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
+                      double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order,
+                      int accumulate) {
+    const int nt = round64(g.N);
+    const size_t shm = (size_t)(g.L + 2 * (nt + 2) + nt + nt / 64 + 2) * sizeof(double);
+    TransportArgs a{g, tau, Jn, In, I, saved, saved_col_stride, desc, cv, order, accumulate};
+    hipLaunchKernelGGL(k_transport, dim3(B), dim3(nt), shm, s, a);
+}
+
+// columns still iterating when the order budget is exhausted
+__global__ void k_finalize(int B, Conv cv, int max_orders) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && cv.active[b]) cv.status[b] = SOSRT_COL_MAXORDERS;
+}
+void launch_finalize(hipStream_t s, int B, Conv cv, int max_orders) {
+    hipLaunchKernelGGL(k_finalize, dim3((B + 127) / 128), dim3(128), 0, s, B, cv, max_orders);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fluxes: one wavefront per (column, layer)    (graphe:157-158, crit:380-381)
+// ------------------------------------------------------------------------------------------
+__global__ void k_fluxes(Grid g, int B, const double* __restrict__ tau_all, const double* __restrict__ I_all,
+                         const ColDesc* __restrict__ desc, int beam_norm, double* __restrict__ fdn,
+                         double* __restrict__ fup) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B * g.L) return;
+    const int lane = threadIdx.x & 63, b = row / g.L, t = row % g.L;
+    const double* I = I_all + (size_t)row * g.D;
+    double sd = 0, su = 0;
+    for (int k = lane; k < g.N; k += 64) {
+        sd += g.wflux_dn[k] * I[k];
+        su += g.wflux_up[k] * I[g.N + k];
+    }
+    sd = wave_sum(sd);
+    su = wave_sum(su);
+    if (lane == 0) {
+        const ColDesc& d = desc[b];
+        const double* tau = tau_all + (size_t)b * g.L;
+        const double F0 = SOSRT_PI / d.mu0;
+        const double fb = beam_norm ? F0 : F0 / (4 * SOSRT_PI);
+        fdn[row] = sd - fb * exp(-tau[t] / d.mu0);
+        fup[row] = su + fb * d.rho * exp(-(2 * tau[g.L - 1] - tau[t]) / d.mu0);
+    }
+}
+void launch_fluxes(hipStream_t s, const Grid& g, int B, const double* tau, const double* I, const ColDesc* desc,
+                   int beam_norm, double* fdn, double* fup) {
+    const int rows = B * g.L;
+    hipLaunchKernelGGL(k_fluxes, dim3((rows + 3) / 4), dim3(256), 0, s, g, B, tau, I, desc, beam_norm, fdn, fup);
+}
+
+// ------------------------------------------------------------------------------------------
+// helper-level kernels (In_limit:70,113)
+// ------------------------------------------------------------------------------------------
+__global__ void k_limit_rows(Grid g, int R, int table, const double* __restrict__ rows, double* __restrict__ out) {
+    const FixTab& ft = g.fix[table];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * ft.idx) return;
+    const int r = e / ft.idx, i = e % ft.idx;
+    double acc = 0;
+    for (int q = 0; q < ft.ns; ++q) acc += ft.C[i * ft.ns + q] * rows[(size_t)r * g.N + ft.s0 + q];
+    out[e] = acc;
+}
+void launch_limit_rows(hipStream_t s, const Grid& g, int R, int table, const double* rows, double* out) {
+    const int n = R * kFixMaxIdx;
+    hipLaunchKernelGGL(k_limit_rows, dim3((n + 127) / 128), dim3(128), 0, s, g, R, table, rows, out);
+}
+
+__global__ void k_asymptotic(int R, int stride, const int* __restrict__ len, const double* __restrict__ J,
+                             const double* __restrict__ tau, const double* __restrict__ tau_t,
+                             const double* __restrict__ mu, double* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int n = len[r];
+    if (n <= 0) { out[r] = 0.0; return; }                       // In_limit:75
+    const double* Jr = J + (size_t)r * stride;
+    const double* tr = tau + (size_t)r * stride;
+    const double m = mu[r], tt = tau_t[r];
+    const double Jl = Jr[n - 1];
+    if (fabs(m) < kMuVerySmall) {
+        double slope = 0;
+        if (n > 1) slope = (Jl - Jr[n - 2]) / (tr[n - 1] - tr[n - 2]);
+        out[r] = -Jl + m * slope;
+        return;
+    }
+    // general slice: tau_t need not be tau[n-1]; the window is every index with tau >= tau_t - 5|mu|
+    const double lim = tt - 5 * fabs(m);
+    double acc = 0, fprev = 0, xprev = 0;
+    bool have = false, bad = false;
+    for (int s = 0; s < n; ++s) {
+        if (!(tr[s] >= lim)) continue;
+        const double f = Jr[s] * exp((tt - tr[s]) / m);
+        bad = bad || !isfinite(f);
+        if (have) acc += (tr[s] - xprev) * (f + fprev) / 2;
+        have = true; fprev = f; xprev = tr[s];
+    }
+    if (!have || bad) { out[r] = -Jl; return; }
+    out[r] = -acc / m;
+}
+void launch_asymptotic(hipStream_t s, int R, int stride, const int* len, const double* J, const double* tau,
+                       const double* tau_t, const double* mu, double* out) {
+    hipLaunchKernelGGL(k_asymptotic, dim3((R + 63) / 64), dim3(64), 0, s, R, stride, len, J, tau, tau_t, mu, out);
+}
+
+}  // namespace sosrt

@@ -1,0 +1,89 @@
+// Device-side data structures and kernel launchers (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "plan.hpp"
+
+namespace sosrt {
+
+constexpr int kMaxZones = 3;
+
+// One independent SOS problem as the kernels see it: a zone table instead of the reference's
+// three copies of every formula (spec:113-449).
+struct alignas(16) ColDesc {
+    int nz;                    // zones, top to bottom
+    int r0[kMaxZones];         // first / last row of each zone
+    int r1[kMaxZones];
+    int mix[kMaxZones];        // 1: aerosol slab (phase mix of spec:149,321)
+    int nfix[kMaxZones];       // rewritten downward angles next to mu=0- (spec:342-345,361-364,380-383)
+    int fixtab[kMaxZones];     // which extrapolation table
+    int surface;               // SOSRT_SURFACE_*
+    int geom;
+    double mu0, rho, T, tau_bottom;
+    double wa, wr, fa, fr;     // single-scattering albedos, slab mixing fractions (spec:50-53,149)
+    double ca[kMaxZones];      // Jn coefficient on In_1 @ W_atm per zone (spec:321,323)
+    double cr[kMaxZones];      // Jn coefficient on In_1 @ W_aer per zone
+};
+
+struct FixTab {
+    int idx, s0, ns, pad;
+    double C[kFixMaxIdx * kFixMaxSrc];
+};
+
+// per-column scalars as uploaded by sosrt_set_columns (structure of arrays)
+struct ColScalars {
+    const int* idx_up;
+    const int* idx_down;
+    const double* mu0;
+    const double* rho;
+    const double* alb_atm;
+    const double* alb_aer;
+    const double* dtau_atm;
+    const double* dtau_aer;
+    const double* T;
+};
+
+struct Grid {
+    int L, N, D;
+    int Dp;                    // D rounded up to the GEMM k-chunk
+    int Wld;                   // leading dimension of the folded matrices (multiple of the GEMM column tile)
+    const double* mu;          // [D]
+    const double* Wa;          // [Dp][Wld]
+    const double* Wr;          // [Dp][Wld]
+    const FixTab* fix;         // [4]
+    const int* small_lanes;
+    int nsmall;
+    const double* wflux_dn;    // [N]
+    const double* wflux_up;    // [N]
+};
+
+struct Conv {
+    int* active;               // [B] 1 while the column still iterates
+    int* norders;              // [B] n of spec:307
+    int* status;               // [B]
+    int* nactive;              // [1]
+    double* ratio;             // [B] last value of the spec:309 test
+    double tol;
+};
+
+constexpr int GEMM_BM = 64, GEMM_BN = 128, GEMM_KC = 16;
+
+void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
+                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r);
+void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, const double* P0a, const double* P0r,
+                        const ColDesc* desc, double* I1_out, double* I_out, double* saved, size_t saved_col_stride,
+                        Conv cv, int do_conv);
+void launch_gemm(hipStream_t s, const Grid& g, const double* A, const double* W, const double* coef,
+                 const int* rowlist, int nrows, double* C, int accumulate, const int* active);
+void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
+                    const ColDesc* desc, const int* active);
+void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
+                      double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate);
+void launch_fluxes(hipStream_t s, const Grid& g, int B, const double* tau, const double* I, const ColDesc* desc,
+                   int beam_norm, double* fdn, double* fup);
+void launch_limit_rows(hipStream_t s, const Grid& g, int R, int table, const double* rows, double* out);
+void launch_asymptotic(hipStream_t s, int R, int stride, const int* len, const double* J, const double* tau,
+                       const double* tau_t, const double* mu, double* out);
+void launch_finalize(hipStream_t s, int B, Conv cv, int max_orders);
+
+}  // namespace sosrt

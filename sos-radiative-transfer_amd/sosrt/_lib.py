@@ -1,0 +1,83 @@
+"""ctypes binding of libsosrt.so (include/sosrt.h).
+
+The product path has no CPU fallback: if the HIP library has not been built
+the import of anything that computes fails loudly here.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SOSRT_LIB") or os.path.join(os.path.dirname(_HERE), "libsosrt.so")
+
+SOSRT_OK, E_INVALID, E_HIP, E_STATE, E_NOMEM = 0, -1, -2, -3, -4
+COL_OK, COL_INDEXERROR, COL_MAXORDERS = 0, 1, 2
+GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
+SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN = 0, 1, 2
+K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU = 0, 1, 2, 3
+
+_dp = POINTER(c_double)
+_ip = POINTER(c_int)
+
+# name -> (restype, argtypes); every symbol include/sosrt.h declares
+SIGNATURES = {
+    "sosrt_last_error": (c_char_p, []),
+    "sosrt_version": (c_int, []),
+    "sosrt_create": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "sosrt_destroy": (c_int, [c_void_p]),
+    "sosrt_set_stream": (c_int, [c_void_p, c_void_p]),
+    "sosrt_synchronize": (c_int, [c_void_p]),
+    "sosrt_set_grid": (c_int, [c_void_p, c_void_p]),
+    "sosrt_set_phase": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sosrt_set_columns": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 9),
+    "sosrt_first_order": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sosrt_source": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "sosrt_transport": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sosrt_solve": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sosrt_solve_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sosrt_last_solve_stats": (c_int, [c_void_p, _ip, POINTER(c_longlong)]),
+    "sosrt_fluxes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "sosrt_limit_mu_down": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "sosrt_asymptotic_down": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sosrt_plan_weights": (c_int, [c_void_p, c_void_p]),
+    "sosrt_plan_fold": (c_int, [c_void_p, c_int, c_void_p]),
+    "sosrt_plan_fix_table": (c_int, [c_void_p, c_int, _ip, _ip, c_void_p]),
+    "sosrt_plan_fix_count": (c_int, [c_double, c_int]),
+    "sosrt_profile_enable": (c_int, [c_void_p, c_int]),
+    "sosrt_profile_reset": (c_int, [c_void_p]),
+    "sosrt_profile_get": (c_int, [c_void_p, c_int, _dp, POINTER(c_longlong), _dp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libsosrt.so not found at %s: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class SosrtError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc == SOSRT_OK:
+        return
+    msg = lib().sosrt_last_error().decode()
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    raise SosrtError(msg)

@@ -1,0 +1,239 @@
+"""Handle-level Python API over the C ABI (host NumPy arrays in, NumPy arrays out;
+`solve_device` works on resident device buffers, e.g. torch tensors)."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+def _i32(a, n, name):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.shape != (n,):
+        raise ValueError("%s has shape %s, expected (%d,)" % (name, a.shape, n))
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _vec(x, B, name):
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (B,)))
+    return a
+
+
+@dataclass
+class SolveResult:
+    I: np.ndarray                  # [B, L, 2N]
+    n: np.ndarray                  # [B] final order count (spec:307-310)
+    status: np.ndarray             # [B] SOSRT_COL_*
+    I_saved: Optional[np.ndarray]  # [B, max_orders, L, 2N] (slots >= n[b] are zero) or None
+
+
+class Solver:
+    """One sosrt handle: fixed (nb_layers, nb_angles), a direction grid, a pair of phase
+    matrices and a batch of columns."""
+
+    def __init__(self, nb_layers: int, nb_angles: int, max_batch: int = 1, max_orders: int = 64, device: int = 0):
+        self.L, self.N, self.D = int(nb_layers), int(nb_angles), 2 * int(nb_angles)
+        self.max_batch, self.max_orders, self.device = int(max_batch), int(max_orders), int(device)
+        self._h = ctypes.c_void_p()
+        check(lib().sosrt_create(self.device, self.L, self.N, self.max_batch, self.max_orders, ctypes.byref(self._h)))
+        self.B = 0
+        self.mu = None
+        self._P = (None, None)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().sosrt_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup -------------------------------------------------------------
+    def set_stream(self, stream_handle: Optional[int]):
+        check(lib().sosrt_set_stream(self._h, ctypes.c_void_p(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        check(lib().sosrt_synchronize(self._h))
+
+    def set_grid(self, mu):
+        mu = _f64(mu, (self.D,), "mu")
+        check(lib().sosrt_set_grid(self._h, _ptr(mu)))
+        self.mu = mu.copy()
+        self._P = (None, None)
+
+    def set_phase(self, P_atm, P_aer=None):
+        Pa = _f64(P_atm, (self.D, self.D), "P_atm")
+        Pr = None if P_aer is None else _f64(P_aer, (self.D, self.D), "P_aer")
+        check(lib().sosrt_set_phase(self._h, _ptr(Pa), _ptr(Pr)))
+        self._P = (Pa.copy(), None if Pr is None else Pr.copy())
+
+    def same_grid(self, mu):
+        return self.mu is not None and np.array_equal(self.mu, np.asarray(mu, dtype=np.float64))
+
+    def same_phase(self, P_atm, P_aer=None):
+        a, r = self._P
+        if a is None or not np.array_equal(a, P_atm):
+            return False
+        if (r is None) != (P_aer is None):
+            return False
+        return r is None or np.array_equal(r, P_aer)
+
+    def set_columns(self, idx_up, idx_down, mu0, grd_alb, alb_atm, alb_aer, dtau_atm, dtau_aer, tauStar_tot,
+                    surface="specular"):
+        """Three-zone columns (spec:23-53).  Scalars broadcast over the batch."""
+        B = int(np.size(idx_up))
+        sf = {"specular": _lib.SURFACE_SPECULAR, "lambertian": _lib.SURFACE_LAMBERTIAN}.get(surface)
+        if sf is None:
+            raise ValueError("surface must be 'specular' or 'lambertian', got %r" % (surface,))
+        iu = _i32(np.reshape(idx_up, (B,)), B, "idx_up")
+        idn = _i32(np.reshape(idx_down, (B,)), B, "idx_down")
+        v = [_vec(x, B, n) for x, n in ((mu0, "mu0"), (grd_alb, "grd_alb"), (alb_atm, "alb_atm"), (alb_aer, "alb_aer"),
+                                        (dtau_atm, "dtau_atm"), (dtau_aer, "dtau_aer"), (tauStar_tot, "tauStar_tot"))]
+        check(lib().sosrt_set_columns(self._h, B, _lib.GEOM_THREE_ZONE, sf, _ptr(iu), _ptr(idn), *[_ptr(x) for x in v]))
+        self.B = B
+
+    def set_columns_single_slab(self, mu0, alb, tauStar):
+        """Single homogeneous slab over a black surface (I1_In:13-130)."""
+        B = int(np.size(mu0))
+        m, a, t = _vec(mu0, B, "mu0"), _vec(alb, B, "alb"), _vec(tauStar, B, "tauStar")
+        check(lib().sosrt_set_columns(self._h, B, _lib.GEOM_SINGLE_SLAB, _lib.SURFACE_NONE, None, None, _ptr(m), None,
+                                      _ptr(a), None, None, None, _ptr(t)))
+        self.B = B
+
+    # ---- step level ----------------------------------------------------------
+    def first_order(self, tau, P0_atm, P0_aer=None):
+        B = self.B
+        tau = _f64(tau, (B, self.L), "tau")
+        Pa = _f64(P0_atm, (B, self.D), "P0_atm")
+        Pr = None if P0_aer is None else _f64(P0_aer, (B, self.D), "P0_aer")
+        out = np.empty((B, self.L, self.D))
+        check(lib().sosrt_first_order(self._h, B, _ptr(tau), _ptr(Pa), _ptr(Pr), _ptr(out)))
+        return out
+
+    def source(self, In_1):
+        B = self.B
+        x = _f64(In_1, (B, self.L, self.D), "In_1")
+        out = np.empty_like(x)
+        check(lib().sosrt_source(self._h, B, _ptr(x), _ptr(out)))
+        return out
+
+    def transport(self, tau, Jn):
+        B = self.B
+        tau = _f64(tau, (B, self.L), "tau")
+        J = _f64(Jn, (B, self.L, self.D), "Jn")
+        out = np.empty_like(J)
+        st = np.zeros(B, dtype=np.int32)
+        check(lib().sosrt_transport(self._h, B, _ptr(tau), _ptr(J), _ptr(out), _ptr(st)))
+        return out, st
+
+    # ---- column level --------------------------------------------------------
+    def solve(self, tau, P0_atm=None, P0_aer=None, tol=1e-4, I1=None, save_orders=False) -> SolveResult:
+        B = self.B
+        tau = _f64(tau, (B, self.L), "tau")
+        Pa = None if P0_atm is None else _f64(P0_atm, (B, self.D), "P0_atm")
+        Pr = None if P0_aer is None else _f64(P0_aer, (B, self.D), "P0_aer")
+        I1a = None if I1 is None else _f64(I1, (B, self.L, self.D), "I1")
+        I = np.empty((B, self.L, self.D))
+        sv = np.zeros((B, self.max_orders, self.L, self.D)) if save_orders else None
+        n = np.zeros(B, dtype=np.int32)
+        st = np.zeros(B, dtype=np.int32)
+        check(lib().sosrt_solve(self._h, B, _ptr(tau), _ptr(Pa), _ptr(Pr), float(tol), _ptr(I1a), _ptr(I), _ptr(sv),
+                                _ptr(n), _ptr(st)))
+        return SolveResult(I=I, n=n, status=st, I_saved=sv)
+
+    def solve_device(self, d_tau: int, d_P0_atm: int, d_P0_aer: int, d_I_out: int, tol=1e-4, d_I1: int = 0,
+                     d_I_saved: int = 0, d_n_orders: int = 0, d_status: int = 0):
+        """All arguments are device addresses (e.g. torch `tensor.data_ptr()`); work is enqueued on
+        the handle's stream (set_stream) and is complete after synchronize()."""
+        vp = lambda x: ctypes.c_void_p(x) if x else None
+        check(lib().sosrt_solve_dev(self._h, self.B, vp(d_tau), vp(d_P0_atm), vp(d_P0_aer), float(tol), vp(d_I1),
+                                    vp(d_I_out), vp(d_I_saved), vp(d_n_orders), vp(d_status)))
+
+    def last_solve_stats(self):
+        mo = ctypes.c_int()
+        so = ctypes.c_longlong()
+        check(lib().sosrt_last_solve_stats(self._h, ctypes.byref(mo), ctypes.byref(so)))
+        return mo.value, so.value
+
+    def fluxes(self, tau, I, beam_norm="crit"):
+        B = self.B
+        tau = _f64(tau, (B, self.L), "tau")
+        I = _f64(I, (B, self.L, self.D), "I")
+        fd = np.empty((B, self.L))
+        fu = np.empty((B, self.L))
+        check(lib().sosrt_fluxes(self._h, B, _ptr(tau), _ptr(I), 0 if beam_norm == "crit" else 1, _ptr(fd), _ptr(fu)))
+        return fd, fu
+
+    # ---- helper level ----------------------------------------------------------
+    def limit_mu_down(self, rows, idx):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if rows.ndim != 2 or rows.shape[1] != self.N:
+            raise ValueError("rows must be [R, nb_angles]")
+        out = np.empty((rows.shape[0], idx))
+        if idx:
+            check(lib().sosrt_limit_mu_down(self._h, rows.shape[0], int(idx), _ptr(rows), _ptr(out)))
+        return out
+
+    def asymptotic_down(self, J, tau, lens, tau_t, mu):
+        J = np.ascontiguousarray(J, dtype=np.float64)
+        tau = _f64(tau, J.shape, "tau")
+        R, stride = J.shape
+        lens = _i32(lens, R, "len")
+        tt = _f64(tau_t, (R,), "tau_t")
+        m = _f64(mu, (R,), "mu")
+        out = np.empty(R)
+        check(lib().sosrt_asymptotic_down(self._h, R, stride, _ptr(lens), _ptr(J), _ptr(tau), _ptr(tt), _ptr(m), _ptr(out)))
+        return out
+
+    # ---- plan introspection (host only) ----------------------------------------
+    def plan_weights(self):
+        w = np.empty(self.D)
+        check(lib().sosrt_plan_weights(self._h, _ptr(w)))
+        return w
+
+    def plan_fold(self, which=0):
+        W = np.empty((self.D, self.D))
+        check(lib().sosrt_plan_fold(self._h, which, _ptr(W)))
+        return W
+
+    def plan_fix_table(self, idx):
+        s0, ns = ctypes.c_int(), ctypes.c_int()
+        C = np.zeros((max(idx, 1), 5))
+        check(lib().sosrt_plan_fix_table(self._h, int(idx), ctypes.byref(s0), ctypes.byref(ns), _ptr(C)))
+        return s0.value, ns.value, C.reshape(-1)[: idx * ns.value].reshape(idx, ns.value).copy()
+
+    # ---- profiling ---------------------------------------------------------------
+    def profile_enable(self, on=True):
+        check(lib().sosrt_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib().sosrt_profile_reset(self._h))
+
+    def profile_get(self, kernel):
+        ms, cnt, w = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        check(lib().sosrt_profile_get(self._h, kernel, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(w)))
+        return ms.value, cnt.value
+
+
+def fix_count(tau_ref: float, nb_angles: int) -> int:
+    """Number of downward angles next to mu=0 the reference rewrites (I1_In:124-127)."""
+    return lib().sosrt_plan_fix_count(float(tau_ref), int(nb_angles))

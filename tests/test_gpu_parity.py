@@ -1,0 +1,229 @@
+"""Parity of the HIP path (through the C ABI) with the reference's golden vectors and with the
+CPU oracle.  Needs a real MI355X: run with `-m gpu`.
+
+Tolerance: the north star's 1e-10 relative on radiance fields (util.RTOL), element-wise where the
+field carries signal and in units of the field maximum elsewhere.
+"""
+import numpy as np
+import pytest
+
+import sos_oracle as O
+from sosrt import I1_In, In_limit, _lib, inputs
+from sosrt.main import SOS_Aer, SOS_Aer_batch
+from sosrt.solver import Solver
+from util import RTOL, assert_close, column_case, g1_case, golden, oracle_column, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------------------------
+# MFMA contraction: operand / result lane maps, with asymmetric data
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,N,B", [(50, 32, 1), (37, 100, 3), (200, 128, 2)])
+def test_source_function_is_the_dense_product(L, N, B):
+    rng = np.random.default_rng(7 * N + L)
+    mu = inputs.direction_grid(N)
+    P = rng.uniform(0.2, 3.0, (2 * N, 2 * N))            # not symmetric: a transposed tile would show
+    X = rng.uniform(0.0, 1.0, (B, L, 2 * N)) * np.linspace(0.5, 2.0, 2 * N)
+    alb = rng.uniform(0.5, 1.0, B)
+    s = Solver(L, N, max_batch=B)
+    s.set_grid(mu)
+    s.set_phase(P)
+    s.set_columns_single_slab(np.full(B, 0.5), alb, np.full(B, 0.3))
+    J = s.source(X)
+    for b in range(B):
+        ref = O.Jn_NumInt(2, X[b], np.zeros(L), mu, 0.3, 0.5, P, alb[b], N)
+        assert_close(J[b], ref, 1e-13, "Jn column %d" % b)
+    s.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# step level against the reference's own outputs (G1): every a4a / a4b branch
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden("g1_*.npz"), ids=lambda p: p.split("/")[-1][3:-4])
+def test_step_functions_match_reference(path):
+    d, N, P = g1_case(path)
+    tau, mu, tS, mu0, alb = d["tau"], d["mu"], float(d["tauStar"]), float(d["mu0"]), float(d["alb"])
+    assert_close(I1_In.I1_NumInt(tau, mu, tS, mu0, d["P0"], alb, N), d["I1"], RTOL, "I1_NumInt")
+    In_1, n = d["I1"], 2
+    while "In_%d" % n in d:
+        Jn = I1_In.Jn_NumInt(n, In_1, tau, mu, tS, mu0, P, alb, N)
+        assert_close(Jn, d["Jn_%d" % n], RTOL, "Jn_NumInt n=%d" % n)
+        In = I1_In.In_NumInt(n, d["Jn_%d" % n], In_1, tau, mu, tS, mu0, P, alb, N, 0, 0)
+        assert_close(In, d["In_%d" % n], RTOL, "In_NumInt n=%d" % n)
+        In_1 = d["In_%d" % n]
+        n += 1
+
+
+def test_helpers_match_reference():
+    d = np.load(golden("g2_helpers.npz")[0])
+    for i in range(int(d["n_asym"])):
+        tt, mu, r = d["a%d_par" % i]
+        v = In_limit.improved_asymptotic_downward_radiance(d["a%d_J" % i], d["a%d_tau" % i], tt, mu)
+        assert v == pytest.approx(r, rel=1e-12, abs=0), i
+    assert In_limit.improved_asymptotic_downward_radiance(np.zeros(0), np.zeros(0), 0.1, -2e-3) == 0.0
+    for i in range(int(d["n_lim"])):
+        N, idx = (int(x) for x in d["l%d_Nidx" % i])
+        row, mud = d["l%d_row" % i], np.linspace(-1, 0, N)
+        v = np.array([In_limit.improved_limit_mu_down(row, mud, N, idx, k) for k in range(idx)])
+        assert_close(v, d["l%d_vals" % i], 1e-10 if N <= 256 else 5e-9, "improved_limit_mu_down N=%d idx=%d" % (N, idx))
+        w = np.array([In_limit.limit_mu_down(row, mud, N, idx, k) for k in range(idx)])
+        assert np.array_equal(w, d["l%d_lin" % i])
+    for N, m1, m2 in d["mu_approx"]:
+        assert In_limit.mu_approx_In(inputs.direction_grid(int(N)), int(N)) == (int(m1), int(m2))
+
+
+def test_index_error_like_the_reference():
+    N, L = 16, 6
+    mu = inputs.direction_grid(N)
+    tau = np.linspace(0, 0.3, L)
+    Jn = np.zeros((L, 2 * N))
+    Jn[:, N:] = 50.0 * (-1.0) ** np.arange(N)
+    with pytest.raises(IndexError):
+        O.In_NumInt(2, Jn, None, tau, mu, 0.3, 0.5, None, 1.0, N, literal=False)
+    with pytest.raises(IndexError):
+        I1_In.In_NumInt(2, Jn, None, tau, mu, 0.3, 0.5, np.ones((2 * N, 2 * N)), 1.0, N, 0, 0)
+
+
+# ----------------------------------------------------------------------------------------------
+# column level against the reference (G3 specular, G6 Lambertian n >= 2, G4 digest at C2 shape)
+# ----------------------------------------------------------------------------------------------
+def _solve_fixture(c, I1=None, max_orders=64):
+    s = Solver(c["L"], c["N"], max_batch=1, max_orders=max_orders)
+    s.set_grid(c["mu"])
+    s.set_phase(c["P_atm"], c["P_aer"])
+    s.set_columns([c["idx_up"]], [c["idx_down"]], c["mu0"], c["grd_alb"], c["alb_atm"], c["alb_aer"], c["dtau_atm"],
+                  c["dtau_aer"], c["tauStar_atm"] + c["tauStar_aer"], surface=c["surface"])
+    r = s.solve(c["tau"][None], c["P0_atm"][None], c["P0_aer"][None], I1=None if I1 is None else I1[None], save_orders=True)
+    fd, fu = s.fluxes(c["tau"][None], r.I)
+    s.close()
+    return r, fd[0], fu[0]
+
+
+@pytest.mark.parametrize("path", golden("g3_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
+def test_specular_column_matches_reference(path):
+    d, c = column_case(path)
+    r, fd, fu = _solve_fixture(c)
+    assert r.status[0] == _lib.COL_OK and r.n[0] == c["n"]
+    assert_close(r.I[0], d["I"], RTOL, "I")
+    for k in range(c["n"]):
+        assert_close(r.I_saved[0, k], d["I_saved"][k], RTOL, "order %d" % (k + 1))
+    assert not r.I_saved[0, c["n"]:].any()
+    ofd, ofu = O.fluxes(d["I"], c["mu"], c["tau"], c["N"], c["mu0"], c["grd_alb"])
+    assert_close(fd, ofd, 1e-12, "flux down")
+    assert_close(fu, ofu, 1e-12, "flux up")
+
+
+@pytest.mark.parametrize("path", golden("g6_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
+def test_lambertian_orders_match_modified_reference(path):
+    """n >= 2 with the coded sign of lam:399/401, seeded with the fixture's first order (H1, H2)."""
+    d, c = column_case(path)
+    r, _, _ = _solve_fixture(c, I1=d["I_saved"][0])
+    assert r.n[0] == c["n"]
+    for k in range(c["n"]):
+        assert_close(r.I_saved[0, k], d["I_saved"][k], RTOL, "order %d" % (k + 1))
+    assert_close(r.I[0], d["I"], RTOL, "I")
+    assert d["I_saved"][1][-1, c["N"] + 8] < 0        # the reflected upward term is negative, as coded
+
+
+def test_c2_column_matches_reference_digest():
+    d, c = column_case(golden("g4_spec_C2_*.npz")[0])
+    r, _, _ = _solve_fixture(c)
+    N, L = c["N"], c["L"]
+    assert r.n[0] == c["n"]
+    assert_close(r.I[0, 0, N:], d["toa_up"], RTOL, "TOA up")
+    assert_close(r.I[0, L - 1, :N], d["sfc_down"], RTOL, "surface down")
+    assert_close(r.I[0, L // 2], d["I_mid_row"], RTOL, "middle row")
+    assert_close(r.I[0].sum(axis=0), d["col_sum"], RTOL, "column sums")
+    assert_close(r.I_saved[0, :c["n"]].reshape(c["n"], -1).sum(axis=1), d["order_sum"], RTOL, "order sums")
+    assert r.I[0, 0, N:].max() == pytest.approx(0.6983369737935123, rel=1e-11)
+
+
+def test_SOS_Aer_call_surface():
+    r = SOS_Aer(mu0=0.5, nb_layers=50, nb_angles=32, grd_alb=0.15, atm_phase_fun="iso", aer_phase_fun="iso")
+    d = np.load(golden("g3_spec_C1_iso.npz")[0])
+    assert (r.n, r.idx_up, r.idx_down) == (9, 39, 42)
+    assert np.array_equal(r.tau, d["tau"]) and np.array_equal(r.mu, d["mu"])
+    assert_close(r.I, d["I"], RTOL, "I")
+    assert r.I_saved.shape == (9, 50, 64)
+    assert r.I[0, 32:].max() == pytest.approx(0.6862303878773028, rel=1e-12)
+    with pytest.raises(TypeError):
+        SOS_Aer(nb_layer=3)
+    with pytest.raises(NotImplementedError):
+        SOS_Aer(nb_layers=20, nb_angles=16)            # shipped aerosol is 'eva': needs Mie inputs
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded batches against the oracle (ragged convergence, every surface, every idx bucket)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,N,surface", [(40, 32, "specular"), (36, 64, "lambertian"), (30, 100, "specular")])
+def test_seeded_batch_matches_oracle(L, N, surface):
+    rng = np.random.default_rng(1000 + N)
+    B = 6
+    mu0 = rng.uniform(0.2, 1.0, B)
+    taer = np.array([0.01, 0.1, 0.5, 1.0, 2.0, 0.05])
+    rho = np.array([0.0, 0.15, 0.4, 0.8, 0.3, 0.6])
+    walb = np.array([1.0, 0.97, 0.9, 0.95, 0.85, 1.0])
+    mu = inputs.direction_grid(N)
+    P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
+    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    r = SOS_Aer_batch(mu0, taer, rho, tauStar_atm=0.124, alb_aer=walb, nb_layers=L, nb_angles=N, z_up=40, z_down=12,
+                      P_atm=P_atm, P_aer=P_aer, surface=surface, save_orders=False, max_orders=200)
+    for b in range(B):
+        P0a = inputs.phase_function("rayleigh", N, mu, mu0[b])[0]
+        P0r = inputs.phase_function("hg", N, mu, mu0[b], 0.7)[0]
+        col = O.make_column(mu0[b], 120, 40, 12, L, 0.124, taer[b], rho[b], 1.0, walb[b], N, P0a, P_atm, P0r, P_aer,
+                            surface=surface)
+        ref = O.solve_column(col, literal=False)
+        assert r.n[b] == ref.n, (b, r.n[b], ref.n)
+        assert_close(r.I[b], ref.I, RTOL if surface == "specular" else 1e-9, "column %d" % b)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE sizes (C4 shape: L=200, N=128, a sweep of columns): properties + sampled oracle check
+# ----------------------------------------------------------------------------------------------
+def test_c4_sweep_properties_and_sampled_oracle():
+    L, N = 200, 128
+    mu0 = np.linspace(0.2, 1.0, 4)
+    taer = np.geomspace(0.01, 1.0, 4)
+    rho = np.linspace(0.0, 0.8, 4)
+    M0, TA, RH = (x.ravel() for x in np.meshgrid(mu0, taer, rho, indexing="ij"))
+    mu = inputs.direction_grid(N)
+    P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
+    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    kw = dict(tauStar_atm=0.124, alb_aer=0.97, nb_layers=L, nb_angles=N, P_atm=P_atm, P_aer=P_aer, max_orders=128)
+    r = SOS_Aer_batch(M0, TA, RH, save_orders=True, **kw)
+    B = len(M0)
+    assert (r.status == 0).all() and (r.n >= 2).all()
+    # the field is the sum of its orders
+    for b in range(0, B, 7):
+        assert_close(r.I_saved[b, :r.n[b]].sum(axis=0), r.I[b], 1e-13, "sum of orders")
+    # batch invariance: the same columns in reverse order give bit-identical fields
+    r2 = SOS_Aer_batch(M0[::-1], TA[::-1], RH[::-1], **kw)
+    assert np.array_equal(r2.I[::-1], r.I) and np.array_equal(r2.n[::-1], r.n)
+    # more aerosol or a brighter surface never needs fewer orders
+    n3 = r.n.reshape(4, 4, 4)
+    assert (np.diff(n3, axis=2) >= 0).all() and (np.diff(n3, axis=1) >= 0).all()
+    # sampled columns against the (vectorised) oracle
+    for b in (0, 21, 42, 63):
+        P0a = inputs.phase_function("rayleigh", N, mu, M0[b])[0]
+        P0r = inputs.phase_function("hg", N, mu, M0[b], 0.7)[0]
+        col = O.make_column(M0[b], 120, 25, 17, L, 0.124, TA[b], RH[b], 1.0, 0.97, N, P0a, P_atm, P0r, P_aer)
+        ref = O.solve_column(col, literal=False)
+        assert r.n[b] == ref.n
+        assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
+
+
+def test_argument_errors_on_device():
+    s = Solver(20, 16, max_batch=2)
+    s.set_grid(inputs.direction_grid(16))
+    with pytest.raises(_lib.SosrtError):
+        s.source(np.zeros((1, 20, 32)))                  # columns not set
+    with pytest.raises(ValueError):
+        s.set_columns([0], [5], 0.5, 0.1, 1.0, 1.0, 0.01, 0.01, 0.2)   # idx_up must be >= 1
+    with pytest.raises(ValueError):
+        s.set_columns([3], [19], 0.5, 0.1, 1.0, 1.0, 0.01, 0.01, 0.2)  # idx_down must be <= L-2
+    s.set_columns_single_slab(0.5, 1.0, 0.2)
+    with pytest.raises(ValueError):
+        s.first_order(np.zeros((1, 19)), np.zeros((1, 32)))            # wrong tau length
+    s.close()
