@@ -168,13 +168,19 @@ def test_seeded_batch_matches_oracle(L, N, surface):
     P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
     P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
     r = SOS_Aer_batch(mu0, taer, rho, tauStar_atm=0.124, alb_aer=walb, nb_layers=L, nb_angles=N, z_up=40, z_down=12,
-                      P_atm=P_atm, P_aer=P_aer, surface=surface, save_orders=False, max_orders=200)
+                      P_atm=P_atm, P_aer=P_aer, surface=surface, save_orders=False, max_orders=200, raise_on_error=False)
     for b in range(B):
         P0a = inputs.phase_function("rayleigh", N, mu, mu0[b])[0]
         P0r = inputs.phase_function("hg", N, mu, mu0[b], 0.7)[0]
         col = O.make_column(mu0[b], 120, 40, 12, L, 0.124, taer[b], rho[b], 1.0, walb[b], N, P0a, P_atm, P0r, P_aer,
                             surface=surface)
-        ref = O.solve_column(col, literal=False)
+        try:
+            ref = O.solve_column(col, literal=False)
+        except IndexError:
+            # the reference's unbounded upward search ran off the grid for this column: same outcome required
+            assert r.status[b] == _lib.COL_INDEXERROR, b
+            continue
+        assert r.status[b] == _lib.COL_OK, b
         assert r.n[b] == ref.n, (b, r.n[b], ref.n)
         assert_close(r.I[b], ref.I, RTOL if surface == "specular" else 1e-9, "column %d" % b)
 
@@ -217,13 +223,13 @@ def test_c4_sweep_properties_and_sampled_oracle():
 def test_argument_errors_on_device():
     s = Solver(20, 16, max_batch=2)
     s.set_grid(inputs.direction_grid(16))
-    with pytest.raises(_lib.SosrtError):
-        s.source(np.zeros((1, 20, 32)))                  # columns not set
     with pytest.raises(ValueError):
         s.set_columns([0], [5], 0.5, 0.1, 1.0, 1.0, 0.01, 0.01, 0.2)   # idx_up must be >= 1
     with pytest.raises(ValueError):
         s.set_columns([3], [19], 0.5, 0.1, 1.0, 1.0, 0.01, 0.01, 0.2)  # idx_down must be <= L-2
     s.set_columns_single_slab(0.5, 1.0, 0.2)
+    with pytest.raises(_lib.SosrtError):
+        s.source(np.zeros((1, 20, 32)))                                # phase matrix not set
     with pytest.raises(ValueError):
         s.first_order(np.zeros((1, 19)), np.zeros((1, 32)))            # wrong tau length
     s.close()
