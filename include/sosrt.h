@@ -145,6 +145,11 @@ int sosrt_profile_reset(sosrt_t* h);
 /* total milliseconds and launch count since the last reset (synchronises the stream) */
 int sosrt_profile_get(sosrt_t* h, int kernel, double* total_ms, long long* launches, double* work /*flops or bytes*/);
 
+/* ---- machine peaks measured on this device (roofline denominators) --------------------------- */
+/* which 0: back-to-back v_mfma_f64_16x16x4_f64, TFLOP/s; 1: streaming copy of 1 GiB, GB/s (read+write);
+ * 2: v_fma_f64, TFLOP/s. */
+int sosrt_microbench(sosrt_t* h, int which, double* result);
+
 #ifdef __cplusplus
 }
 #endif

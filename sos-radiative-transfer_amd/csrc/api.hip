@@ -661,6 +661,50 @@ int sosrt_plan_fix_table(sosrt_t* h, int idx, int* s0, int* ns, double* C_out) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// machine peaks
+// ---------------------------------------------------------------------------------------------
+int sosrt_microbench(sosrt_t* h, int which, double* result) {
+    if (int e = need_gpu(h)) return e;
+    if (!result || which < 0 || which > 2) return fail(SOSRT_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const size_t n = (size_t)1 << 27;                 // 1 GiB of doubles per buffer for the copy test
+    double *a = nullptr, *b = nullptr;
+    int rc = 0;
+    auto body = [&]() -> int {
+        const size_t na = which == 1 ? n : 16;
+        if (int e = dalloc(&a, na)) return e;
+        if (which == 1) { if (int e = dalloc(&b, na)) return e; HIPCHK(hipMemsetAsync(a, 0, na * sizeof(double), s)); }
+        const int iters = 20000;
+        double best = 0;
+        for (int rep = 0; rep < 4; ++rep) {
+            HIPCHK(hipEventRecord(e0, s));
+            launch_bench(s, which, a, b, na, iters);
+            HIPCHK(hipEventRecord(e1, s));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            double v;
+            if (which == 0) v = 2048.0 * 4 * (double)iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;        // TFLOP/s
+            else if (which == 1) v = 2.0 * na * sizeof(double) / (ms * 1e-3) / 1e9;                  // GB/s read+write
+            else v = 2048.0 * 256 * (double)iters * 16 * 2.0 / (ms * 1e-3) / 1e12;                   // TFLOP/s
+            if (rep > 0 && v > best) best = v;
+        }
+        *result = best;
+        return 0;
+    };
+    rc = body();
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // profiling
 // ---------------------------------------------------------------------------------------------
 int sosrt_profile_enable(sosrt_t* h, int on) {

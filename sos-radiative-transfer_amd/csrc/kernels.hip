@@ -320,19 +320,23 @@ __global__ __launch_bounds__(256) void k_jn_gemm(const double* __restrict__ A, c
     const double* Arow = grow >= 0 ? A + (size_t)grow * D : A;
     const int fr = lane & 15, fk = lane >> 4;
 
-    for (int kc = 0; kc < Dp; kc += GEMM_KC) {
-        // global -> registers
-        double2 a01 = make_double2(0, 0), a23 = make_double2(0, 0);
+    // software pipeline: the global loads of chunk k+1 are in flight while chunk k is multiplied
+    double2 a01, a23, b0, b1, b2, b3;
+    auto gload = [&](int kc) {
+        a01 = make_double2(0, 0); a23 = make_double2(0, 0);
         const int k0 = kc + akq;
         if (grow >= 0) {
             if (k0 + 1 < D) a01 = *reinterpret_cast<const double2*>(Arow + k0);
             if (k0 + 3 < D) a23 = *reinterpret_cast<const double2*>(Arow + k0 + 2);
         }
         const double* Wp = W + (size_t)(kc + bk) * Wld + bn0 + bc;
-        const double2 b0 = *reinterpret_cast<const double2*>(Wp);
-        const double2 b1 = *reinterpret_cast<const double2*>(Wp + 2);
-        const double2 b2 = *reinterpret_cast<const double2*>(Wp + 4);
-        const double2 b3 = *reinterpret_cast<const double2*>(Wp + 6);
+        b0 = *reinterpret_cast<const double2*>(Wp);
+        b1 = *reinterpret_cast<const double2*>(Wp + 2);
+        b2 = *reinterpret_cast<const double2*>(Wp + 4);
+        b3 = *reinterpret_cast<const double2*>(Wp + 6);
+    };
+    gload(0);
+    for (int kc = 0; kc < Dp; kc += GEMM_KC) {
         __syncthreads();   // previous chunk consumed
         *reinterpret_cast<double2*>(&sA[arow * A_LD + akq]) = a01;
         *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2]) = a23;
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(256) void k_jn_gemm(const double* __restrict__ A, c
         *reinterpret_cast<double2*>(sb + 4) = b2;
         *reinterpret_cast<double2*>(sb + 6) = b3;
         __syncthreads();
+        if (kc + GEMM_KC < Dp) gload(kc + GEMM_KC);
 #pragma unroll
         for (int kk = 0; kk < GEMM_KC; kk += 4) {
             double af[4], bf[2];
@@ -452,7 +457,12 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
 // directions: the extrapolation of the last downward angles (In_limit:113-141, here a fixed
 // linear map) and the upward second-difference search and blend (spec:402-409).
 // ------------------------------------------------------------------------------------------
-constexpr int TU = 4;   // rows loaded ahead of the recurrence
+// Rows are processed in chunks of TC: the loads of the next chunk are in flight while the current
+// one is computed, the TC exponentials of a chunk are independent (instruction-level parallelism
+// for the one wave per SIMD a column gives), only the TC fused multiply-adds of the recurrence are
+// sequential, and the workgroup meets once per chunk to exchange rows.  A chunk never crosses a
+// zone boundary, because the next zone restarts from the final (rewritten / blended) row.
+constexpr int TC = 8;
 
 struct TransportArgs {
     Grid g;
@@ -468,100 +478,140 @@ struct TransportArgs {
     int accumulate;
 };
 
-__global__ void k_transport(TransportArgs a) {
+// The chunk loops are written branch-free (clamped row indices, selects instead of predicated
+// blocks, reciprocal of mu hoisted) so that the compiler can interleave the TC independent
+// exp / source-term chains of a chunk: with one wave per SIMD, instruction-level parallelism
+// is the only latency hiding there is.
+template <int MAXT, bool ACC, bool SAVED>
+__global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     const int b = blockIdx.x;
-    if (a.accumulate && !a.cv.active[b]) return;
+    if (ACC && !a.cv.active[b]) return;
     const Grid& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int L = g.L, N = g.N, D = g.D;
     const int SR = blockDim.x + 2;
     extern __shared__ double sm[];
     double* s_tau = sm;                      // [L]
-    double* s_row = s_tau + L;               // [2][SR]
-    double* s_sfc = s_row + 2 * SR;          // [blockDim]
-    double* s_red = s_sfc + blockDim.x;      // [nw + 1]
+    double* s_rows = s_tau + L;              // [2][TC][SR]
+    double* s_sfc = s_rows + 2 * TC * SR;    // [blockDim]
+    double* s_mup = s_sfc + blockDim.x;      // [blockDim] upward half of the direction grid
+    double* s_red = s_mup + blockDim.x;      // [nw + 1]
     __shared__ ColDesc d;                    // dynamically indexed: keep it out of scratch
     if (tid == 0) d = a.desc[b];
-    const double* tau = a.tau + (size_t)b * L;
-    const double* J = a.Jn + (size_t)b * L * D;
-    double* In = a.In + (size_t)b * L * D;
-    double* Iacc = a.accumulate ? a.I + (size_t)b * L * D : nullptr;
-    double* sv = a.saved ? a.saved + (size_t)b * a.saved_col_stride : nullptr;
+    s_mup[tid] = tid < N ? g.mu[N + tid] : 1.0;
+    const double* __restrict__ tau = a.tau + (size_t)b * L;
+    const double* __restrict__ J = a.Jn + (size_t)b * L * D;
+    double* __restrict__ In = a.In + (size_t)b * L * D;
+    double* __restrict__ Iacc = ACC ? a.I + (size_t)b * L * D : nullptr;
+    double* __restrict__ sv = SAVED ? a.saved + (size_t)b * a.saved_col_stride : nullptr;
     for (int t = tid; t < L; t += blockDim.x) s_tau[t] = tau[t];
-    if (tid < 2) { s_row[blockDim.x + tid] = 0; s_row[SR + blockDim.x + tid] = 0; }
     __syncthreads();
 
     const bool valid = tid < N;
-    double rdn = 0, rup = 0;
-    int p = 0;
+    const int tidc = valid ? tid : N - 1;    // clamped lane for loads of idle threads
+    double rdn_v = 0, rdn_i = 1, rup_v = 0, rup_i = 1;
+    int par = 0;                             // LDS row-buffer parity: one barrier per chunk
 
     // =============================== downward ===============================
     {
-        const int m = tid;
+        const int m = tidc;
         const double mu = valid ? g.mu[m] : -1.0;
-        const bool tr = valid && m <= N - 2;
+        const bool tr = valid && tid <= N - 2;
         const bool small = tr && fabs(mu) < kMuThreshold;       // spec:333
         const bool stdl = tr && !small;
+        const double rmu = 1.0 / (stdl ? mu : -1.0);
         double Dv = 0, Jprev = 0;
-        int z = 0, nfx = d.nfix[0], s0 = 0, ns = 0;
+        int z = 0, nfx = 0, s0 = 0, ns = 0;
         double c[kFixMaxSrc] = {0, 0, 0, 0, 0};
         bool fixlane = false;
         auto load_fix = [&](int zz) {
             nfx = d.nfix[zz];
             const FixTab& ft = g.fix[d.fixtab[zz]];
             s0 = ft.s0; ns = ft.ns;
-            fixlane = valid && nfx > 0 && m >= N - nfx;
+            fixlane = valid && nfx > 0 && tid >= N - nfx;
             if (fixlane) {
-                const int i = N - 1 - m;
+                const int i = N - 1 - tid;
 #pragma unroll
                 for (int q = 0; q < kFixMaxSrc; ++q) c[q] = q < ns ? ft.C[i * ns + q] : 0.0;
             }
         };
         load_fix(0);
-        for (int t0 = 0; t0 < L; t0 += TU) {
-            double Jr[TU], Ir[TU], Sr[TU];
+        double Jn_[TC], In_[TC], Sn_[TC];
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int t = t0 + u;
-                const bool ok = valid && t < L;
-                Jr[u] = ok ? J[(size_t)t * D + m] : 0.0;
-                Ir[u] = (ok && Iacc) ? Iacc[(size_t)t * D + m] : 0.0;
-                Sr[u] = (ok && small) ? In[(size_t)t * D + m] : 0.0;   // written by k_smallmu
+        for (int u = 0; u < TC; ++u) Sn_[u] = 0.0;
+        auto prefetch = [&](int t0) {
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = min(t0 + u, L - 1);
+                Jn_[u] = J[(size_t)t * D + m];
+                In_[u] = ACC ? Iacc[(size_t)t * D + m] : 0.0;
             }
+            if (small) {                                            // one masked region: values written by k_smallmu
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int t = t0 + u;
-                if (t >= L) break;
-                if (t > d.r1[z]) { ++z; load_fix(z); }
-                const double Jt = Jr[u];
-                if (stdl && t > 0) {
-                    const double dl = s_tau[t] - s_tau[t - 1];
-                    const double E = exp(dl / mu);
-                    Dv = Dv * E - (dl / 2) * (Jprev * E + Jt) / mu;
+                for (int u = 0; u < TC; ++u) Sn_[u] = In[(size_t)min(t0 + u, L - 1) * D + m];
+            }
+        };
+        prefetch(0);
+        for (int t0 = 0; t0 < L;) {
+            if (t0 > d.r1[z]) { ++z; load_fix(z); }
+            int len = d.r1[z] - t0 + 1;
+            if (len > TC) len = TC;
+            double Jc[TC], Ic[TC], Sc[TC], E[TC], cc[TC], v[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) { Jc[u] = Jn_[u]; Ic[u] = In_[u]; Sc[u] = Sn_[u]; }
+            prefetch(min(t0 + len, L - 1));
+            // independent part: attenuation and source term of every row of the chunk
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = min(t0 + u, L - 1);
+                const double dl = s_tau[t] - s_tau[max(t - 1, 0)];   // 0 at t = 0: E = 1, source 0
+                const double Jp = u == 0 ? Jprev : Jc[u - 1];
+                E[u] = exp(dl * rmu);
+                cc[u] = -(dl * 0.5) * (Jp * E[u] + Jc[u]) * rmu;
+            }
+            // sequential part
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const double Dn = Dv * E[u] + cc[u];
+                Dv = u < len ? Dn : Dv;
+                v[u] = stdl ? Dn : (small ? Sc[u] : 0.0);
+            }
+            if (nfx > 0) {                                              // block-uniform
+                double* rows = s_rows + par * TC * SR;
+#pragma unroll
+                for (int u = 0; u < TC; ++u) rows[u * SR + tid] = v[u];
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    double acc = 0;
+#pragma unroll
+                    for (int q = 0; q < kFixMaxSrc; ++q) acc += c[q] * rows[u * SR + s0 + min(q, ns - 1)];
+                    v[u] = fixlane ? acc : v[u];
                 }
-                double v = stdl ? Dv : (small ? Sr[u] : 0.0);
-                if (nfx > 0) {                                      // block-uniform
-                    if (valid) s_row[p * SR + m] = v;
-                    __syncthreads();
-                    if (fixlane) {
-                        double acc = 0;
+                par ^= 1;
+            }
+            if (valid) {
 #pragma unroll
-                        for (int q = 0; q < kFixMaxSrc; ++q)
-                            if (q < ns) acc += c[q] * s_row[p * SR + s0 + q];
-                        v = acc;
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 + u;
+                    if (u < len) {
+                        In[(size_t)t * D + m] = v[u];
+                        if (ACC) Iacc[(size_t)t * D + m] = Ic[u] + v[u];
+                        if (SAVED) sv[(size_t)t * D + m] = v[u];
                     }
-                    p ^= 1;
                 }
-                double Inew = 0;
-                if (valid) {
-                    In[(size_t)t * D + m] = v;
-                    if (Iacc) { Inew = Ir[u] + v; Iacc[(size_t)t * D + m] = Inew; }
-                    if (sv) sv[(size_t)t * D + m] = v;
-                }
-                if (t == L - 1) { s_sfc[tid] = v; rdn = v / Inew; }
-                if (t == d.r1[z]) Dv = v;                           // the next zone starts from the final row (spec:359,378)
-                Jprev = Jt;
             }
+            double vlast = 0, Jlast = 0, Ilast = 0;
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                vlast = u == len - 1 ? v[u] : vlast;
+                Jlast = u == len - 1 ? Jc[u] : Jlast;
+                Ilast = u == len - 1 ? Ic[u] + v[u] : Ilast;
+            }
+            Jprev = Jlast;
+            if (t0 + len == L) { s_sfc[tid] = vlast; rdn_v = vlast; rdn_i = Ilast; }
+            if (t0 + len - 1 == d.r1[z]) Dv = vlast;        // the next zone starts from the final row (spec:359,378)
+            t0 += len;
         }
     }
     __syncthreads();
@@ -585,79 +635,110 @@ __global__ void k_transport(TransportArgs a) {
     // =============================== upward ===============================
     int status = SOSRT_COL_OK;
     {
-        const int j = tid;
-        const double mu = (valid && j > 0) ? g.mu[N + j] : 1.0;
-        const bool tr = valid && j > 0;
+        const int j = tidc;
+        const bool tr = valid && tid > 0;
+        const double mu = tr ? s_mup[j] : 1.0;
+        const double rmu = 1.0 / mu;
         double U = Bv, Jnext = 0;
         int z = d.nz - 1;
-        for (int t0 = L - 1; t0 >= 0; t0 -= TU) {
-            double Jr[TU], Ir[TU];
+        double Jn_[TC], In_[TC];
+        auto prefetch = [&](int t0) {
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int t = t0 - u;
-                const bool ok = valid && t >= 0;
-                Jr[u] = ok ? J[(size_t)t * D + N + j] : 0.0;
-                Ir[u] = (ok && Iacc) ? Iacc[(size_t)t * D + N + j] : 0.0;
+            for (int u = 0; u < TC; ++u) {
+                const int t = max(t0 - u, 0);
+                Jn_[u] = J[(size_t)t * D + N + j];
+                In_[u] = ACC ? Iacc[(size_t)t * D + N + j] : 0.0;
+            }
+        };
+        prefetch(L - 1);
+        for (int t0 = L - 1; t0 >= 0;) {
+            if (t0 < d.r0[z]) --z;
+            int len = t0 - d.r0[z] + 1;
+            if (len > TC) len = TC;
+            const int zr1 = d.r1[z];
+            double Jc[TC], Ic[TC], E[TC], cc[TC], v[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) { Jc[u] = Jn_[u]; Ic[u] = In_[u]; }
+            prefetch(max(t0 - len, 0));
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = max(t0 - u, 0);
+                const double dl = s_tau[min(t + 1, L - 1)] - s_tau[t];   // 0 at t = L-1: E = 1, source 0
+                const double Jx = u == 0 ? Jnext : Jc[u - 1];
+                E[u] = exp(-dl * rmu);
+                // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
+                const double src = (dl * 0.5) * (Jc[u] + Jx * E[u]) * rmu;
+                cc[u] = (t == zr1) ? 0.0 : src;
             }
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int t = t0 - u;
-                if (t < 0) break;
-                if (t < d.r0[z]) --z;
-                const double Jt = Jr[u];
-                if (tr && t < L - 1) {
-                    const double dl = s_tau[t + 1] - s_tau[t];
-                    const double E = exp(-dl / mu);
-                    if (t == d.r1[z]) U = U * E;                    // first row of a zone: attenuate only (spec:413-419,433-439)
-                    else U = U * E + (dl / 2) * (Jt + Jnext * E) / mu;
-                }
-                const double r = (j == 0) ? Jt : U;                 // spec:401
-                if (valid) s_row[p * SR + j] = r;
-                __syncthreads();
-                // second-difference search from the first upward angle (spec:403-406)
-                const double* row = s_row + p * SR;
-                int ks = -1;
-                {
-                    const int jj = lane;
-                    bool stop = false;
-                    if (jj >= 1 && jj <= N - 3) {
-                        const double x0 = row[jj], x1 = row[jj + 1], x2 = row[jj + 2];
-                        stop = !(fabs((x0 - x1) - (x1 - x2)) > 0.0001);
-                    }
-                    const unsigned long long mk = __ballot(stop);
-                    if (mk) ks = __ffsll((long long)mk) - 1;
+            for (int u = 0; u < TC; ++u) {
+                const double Un = U * E[u] + cc[u];
+                U = u < len ? Un : U;
+                v[u] = (tid == 0) ? Jc[u] : Un;                         // spec:401
+            }
+            double* rows = s_rows + par * TC * SR;
+#pragma unroll
+            for (int u = 0; u < TC; ++u) rows[u * SR + tid] = v[u];
+            __syncthreads();
+            par ^= 1;
+            // second-difference search from the first upward angle (spec:403-406), all rows of the chunk
+            unsigned long long mk[TC];
+            const int lc = min(max(lane, 1), N - 3);
+            const bool cand = lane >= 1 && lane <= N - 3;
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const double* row = rows + u * SR;
+                const double x0 = row[lc], x1 = row[lc + 1], x2 = row[lc + 2];
+                mk[u] = __ballot(cand && !(fabs((x0 - x1) - (x1 - x2)) > 0.0001));
+            }
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                if (u < len) {
+                    const double* row = rows + u * SR;
+                    int ks = -1;
+                    if (mk[u]) ks = __ffsll((long long)mk[u]) - 1;
                     else {
                         for (int q = 64; q <= N - 3; ++q) {
                             const double x0 = row[q], x1 = row[q + 1], x2 = row[q + 2];
                             if (!(fabs((x0 - x1) - (x1 - x2)) > 0.0001)) { ks = q; break; }
                         }
+                        if (ks < 0) status = SOSRT_COL_INDEXERROR;       // the reference raises IndexError here
                     }
+                    const int kf = max(ks, 0) + 1;
+                    const double w = mu / s_mup[kf];
+                    const double bl = (1 - w) * row[0] + w * row[kf];    // spec:407-409
+                    v[u] = (tr && tid < kf) ? bl : v[u];
                 }
-                if (ks < 0) { status = SOSRT_COL_INDEXERROR; break; }    // the reference raises IndexError here
-                const int kf = ks + 1;
-                double v = r;
-                if (tr && j < kf) {
-                    const double w = mu / g.mu[N + kf];
-                    v = (1 - w) * row[0] + w * row[kf];                 // spec:407-409
-                }
-                p ^= 1;
-                double Inew = 0;
-                if (valid) {
-                    In[(size_t)t * D + N + j] = v;
-                    if (Iacc) { Inew = Ir[u] + v; Iacc[(size_t)t * D + N + j] = Inew; }
-                    if (sv) sv[(size_t)t * D + N + j] = v;
-                }
-                if (t == 0) rup = v / Inew;
-                if (t == d.r0[z] && z > 0 && tr) U = v;                 // blended row feeds the zone above
-                Jnext = Jt;
             }
             if (status != SOSRT_COL_OK) break;
+            if (valid) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 - u;
+                    if (u < len) {
+                        In[(size_t)t * D + N + j] = v[u];
+                        if (ACC) Iacc[(size_t)t * D + N + j] = Ic[u] + v[u];
+                        if (SAVED) sv[(size_t)t * D + N + j] = v[u];
+                    }
+                }
+            }
+            double vlast = 0, Jlast = 0, Ilast = 0;
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                vlast = u == len - 1 ? v[u] : vlast;
+                Jlast = u == len - 1 ? Jc[u] : Jlast;
+                Ilast = u == len - 1 ? Ic[u] + v[u] : Ilast;
+            }
+            Jnext = Jlast;
+            if (t0 - len + 1 == 0) { rup_v = vlast; rup_i = Ilast; }
+            if (t0 - len + 1 == d.r0[z] && z > 0 && tr) U = vlast;       // blended row feeds the zone above
+            t0 -= len;
         }
     }
     if (status != SOSRT_COL_OK) {
         if (tid == 0) {
             a.cv.status[b] = status;
-            if (a.accumulate) {
+            if (ACC) {
                 a.cv.active[b] = 0;
                 a.cv.norders[b] = a.order;
                 atomicSub(a.cv.nactive, 1);
@@ -665,9 +746,9 @@ __global__ void k_transport(TransportArgs a) {
         }
         return;
     }
-    if (a.accumulate) {
-        const double ra = block_pymax(rup, valid, s_red);
-        const double rb = block_pymax(rdn, valid, s_red);
+    if (ACC) {
+        const double ra = block_pymax(rup_v / rup_i, valid, s_red);
+        const double rb = block_pymax(rdn_v / rdn_i, valid, s_red);
         const double r = outer_pymax(ra, rb);
         if (tid == 0) {
             a.cv.ratio[b] = r;
@@ -682,13 +763,27 @@ __global__ void k_transport(TransportArgs a) {
     }
 }
 
+template <int MAXT>
+static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm, const TransportArgs& a) {
+    if (a.accumulate) {
+        if (a.saved) hipLaunchKernelGGL((k_transport<MAXT, true, true>), grid, block, shm, s, a);
+        else hipLaunchKernelGGL((k_transport<MAXT, true, false>), grid, block, shm, s, a);
+    } else {
+        hipLaunchKernelGGL((k_transport<MAXT, false, false>), grid, block, shm, s, a);
+    }
+}
+
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order,
                       int accumulate) {
     const int nt = round64(g.N);
-    const size_t shm = (size_t)(g.L + 2 * (nt + 2) + nt + nt / 64 + 2) * sizeof(double);
-    TransportArgs a{g, tau, Jn, In, I, saved, saved_col_stride, desc, cv, order, accumulate};
-    hipLaunchKernelGGL(k_transport, dim3(B), dim3(nt), shm, s, a);
+    const size_t shm = (size_t)(g.L + 2 * TC * (nt + 2) + 2 * nt + nt / 64 + 2) * sizeof(double);
+    TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate};
+    // the register budget follows the workgroup size: one column needs few waves, so they may be fat
+    if (nt <= 128) launch_transport_t<128>(s, dim3(B), dim3(nt), shm, a);
+    else if (nt <= 256) launch_transport_t<256>(s, dim3(B), dim3(nt), shm, a);
+    else if (nt <= 512) launch_transport_t<512>(s, dim3(B), dim3(nt), shm, a);
+    else launch_transport_t<1024>(s, dim3(B), dim3(nt), shm, a);
 }
 
 // columns still iterating when the order budget is exhausted
@@ -783,6 +878,51 @@ __global__ void k_asymptotic(int R, int stride, const int* __restrict__ len, con
 void launch_asymptotic(hipStream_t s, int R, int stride, const int* len, const double* J, const double* tau,
                        const double* tau_t, const double* mu, double* out) {
     hipLaunchKernelGGL(k_asymptotic, dim3((R + 63) / 64), dim3(64), 0, s, R, stride, len, J, tau, tau_t, mu, out);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// machine peaks measured on the box (denominators of the roofline fractions)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bench_mfma_f64(double* out, int iters) {
+    f64x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (f64x4){0, 0, 0, 0};
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double sres = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sres += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (sres == 12345.678) out[0] = sres;          // keeps the loop alive
+}
+
+__global__ __launch_bounds__(256) void k_bench_fma_f64(double* out, int iters) {
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 1e-3 * (threadIdx.x + i);
+    const double a = 1.0 - 1e-12, b = 1e-12;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = fma(x[i], a, b);
+    }
+    double sres = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sres += x[i];
+    if (sres == 12345.678) out[0] = sres;
+}
+
+__global__ __launch_bounds__(256) void k_bench_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+void launch_bench(hipStream_t s, int which, double* a, double* b, size_t n, int iters) {
+    if (which == 0) hipLaunchKernelGGL(k_bench_mfma_f64, dim3(2048), dim3(256), 0, s, a, iters);
+    else if (which == 1) hipLaunchKernelGGL(k_bench_copy, dim3(2048), dim3(256), 0, s, (const double2*)a, (double2*)b, n / 2);
+    else hipLaunchKernelGGL(k_bench_fma_f64, dim3(2048), dim3(256), 0, s, a, iters);
 }
 
 }  // namespace sosrt

@@ -221,6 +221,12 @@ class Solver:
         check(lib().sosrt_plan_fix_table(self._h, int(idx), ctypes.byref(s0), ctypes.byref(ns), _ptr(C)))
         return s0.value, ns.value, C.reshape(-1)[: idx * ns.value].reshape(idx, ns.value).copy()
 
+    def microbench(self, which):
+        """0: FP64 MFMA TFLOP/s, 1: streaming copy GB/s, 2: FP64 FMA TFLOP/s, measured on this device."""
+        r = ctypes.c_double()
+        check(lib().sosrt_microbench(self._h, int(which), ctypes.byref(r)))
+        return r.value
+
     # ---- profiling ---------------------------------------------------------------
     def profile_enable(self, on=True):
         check(lib().sosrt_profile_enable(self._h, 1 if on else 0))

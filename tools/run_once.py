@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One solve of the bench sweep (for rocprofv3 runs): python3 tools/run_once.py [columns] [solves]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sos-radiative-transfer_amd"))
+import numpy as np
+import torch
+
+import bench
+from sosrt.solver import Solver
+
+cols = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+solves = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+w = bench.build_sweep(cols, 200, 128, 0, 1)
+B, L, N = w["B"], w["L"], w["N"]
+dev = torch.device("cuda", 0)
+s = Solver(L, N, max_batch=B, max_orders=256)
+s.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+s.set_grid(w["mu"]); s.set_phase(w["P_atm"], w["P_aer"])
+s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
+              w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
+d_tau = torch.from_numpy(w["tau"]).to(dev); d_P0a = torch.from_numpy(w["P0a"]).to(dev); d_P0r = torch.from_numpy(w["P0r"]).to(dev)
+d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev)
+d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+for _ in range(solves):
+    s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr())
+    torch.cuda.synchronize()
+print("orders", int((d_n.cpu().numpy() - 1).sum()), "max", int(d_n.max().item()))
