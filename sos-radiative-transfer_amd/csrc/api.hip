@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -68,7 +69,8 @@ struct sosrt_handle {
     int nslab = 0;
     // device: fields (internal)
     double *d_tau = nullptr, *d_P0a = nullptr, *d_P0r = nullptr;
-    double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr;
+    double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr, *d_E = nullptr;
+    int use_etab = 1;
     // convergence
     int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr;
     double* d_ratio = nullptr;
@@ -165,6 +167,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (!h) return fail(SOSRT_E_NOMEM, "out of host memory");
     h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;
     h->gpu = device >= 0;
+    if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
     Grid& g = h->g;
     g.L = L; g.N = N; g.D = 2 * N;
     g.Dp = (g.D + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
@@ -197,6 +200,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_InA, fe))) return e;
             if ((e = dalloc(&h->d_InB, fe))) return e;
             if ((e = dalloc(&h->d_I, fe))) return e;
+            if ((e = dalloc(&h->d_E, fe))) return e;
             if ((e = dalloc(&h->d_active, mb))) return e;
             if ((e = dalloc(&h->d_norders, mb))) return e;
             if ((e = dalloc(&h->d_status, mb))) return e;
@@ -226,7 +230,7 @@ int sosrt_destroy(sosrt_t* h) {
         if (h->own_stream) hipStreamSynchronize(h->own_stream);
         void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_tau, h->d_P0a,
-                        h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_active, h->d_norders, h->d_status,
+                        h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio};
         for (void* p : ptrs)
             if (p) hipFree(p);
@@ -408,7 +412,7 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     launch_smallmu(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, h->d_desc, nullptr);
     prof_end(h, SOSRT_K_SMALLMU);
     prof_begin(h, SOSRT_K_TRANSPORT);
-    launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0);
+    launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, nullptr);
     prof_end(h, SOSRT_K_TRANSPORT);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(In_out, h->d_InB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -463,6 +467,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
 
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr);
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
+    if (h->use_etab) launch_attenuation(s, g, B, d_tau, h->d_E);
     double* In_1 = h->d_InA;
     double* In = h->d_InB;
     prof_begin(h, SOSRT_K_FIRST);
@@ -495,7 +500,8 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         }
         prof_begin(h, SOSRT_K_TRANSPORT);
         launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out,
-                         d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr, saved_stride, h->d_desc, cv, n, 1);
+                         d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr, saved_stride, h->d_desc, cv, n, 1,
+                         h->use_etab ? h->d_E : nullptr);
         prof_end(h, SOSRT_K_TRANSPORT);
         HIPCHK(hipMemcpyAsync(&h->h_poll[n & 1], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipEventRecord(h->poll_ev[n & 1], s));

@@ -476,13 +476,16 @@ struct TransportArgs {
     Conv cv;
     int order;
     int accumulate;
+    const double* Etab;
 };
 
 // The chunk loops are written branch-free (clamped row indices, selects instead of predicated
 // blocks, reciprocal of mu hoisted) so that the compiler can interleave the TC independent
-// exp / source-term chains of a chunk: with one wave per SIMD, instruction-level parallelism
-// is the only latency hiding there is.
-template <int MAXT, bool ACC, bool SAVED>
+// chains of a chunk: with one wave per SIMD, instruction-level parallelism is the only latency
+// hiding there is.  The loads run two chunks ahead of the recurrence.  With ETAB the layer
+// attenuations exp(-dtau/|mu|) come from a table built once per solve (k_attenuation) instead of
+// 2 L N exponentials per order.
+template <int MAXT, bool ACC, bool SAVED, bool ETAB>
 __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     const int b = blockIdx.x;
     if (ACC && !a.cv.active[b]) return;
@@ -497,10 +500,20 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     double* s_mup = s_sfc + blockDim.x;      // [blockDim] upward half of the direction grid
     double* s_red = s_mup + blockDim.x;      // [nw + 1]
     __shared__ ColDesc d;                    // dynamically indexed: keep it out of scratch
+    __shared__ FixTab s_fix[kMaxZones];      // the extrapolation table of each zone (read at zone changes)
     if (tid == 0) d = a.desc[b];
     s_mup[tid] = tid < N ? g.mu[N + tid] : 1.0;
+    {
+        const ColDesc& dg = a.desc[b];
+        for (int zz = 0; zz < kMaxZones; ++zz) {
+            const double* src = reinterpret_cast<const double*>(&g.fix[dg.fixtab[zz]]);
+            double* dst = reinterpret_cast<double*>(&s_fix[zz]);
+            for (int i = tid; i < (int)(sizeof(FixTab) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
+        }
+    }
     const double* __restrict__ tau = a.tau + (size_t)b * L;
     const double* __restrict__ J = a.Jn + (size_t)b * L * D;
+    const double* __restrict__ Et = ETAB ? a.Etab + (size_t)b * L * D : nullptr;
     double* __restrict__ In = a.In + (size_t)b * L * D;
     double* __restrict__ Iacc = ACC ? a.I + (size_t)b * L * D : nullptr;
     double* __restrict__ sv = SAVED ? a.saved + (size_t)b * a.saved_col_stride : nullptr;
@@ -526,47 +539,59 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
         bool fixlane = false;
         auto load_fix = [&](int zz) {
             nfx = d.nfix[zz];
-            const FixTab& ft = g.fix[d.fixtab[zz]];
+            const FixTab& ft = s_fix[zz];
             s0 = ft.s0; ns = ft.ns;
             fixlane = valid && nfx > 0 && tid >= N - nfx;
-            if (fixlane) {
-                const int i = N - 1 - tid;
+            const int i = fixlane ? N - 1 - tid : 0;
 #pragma unroll
-                for (int q = 0; q < kFixMaxSrc; ++q) c[q] = q < ns ? ft.C[i * ns + q] : 0.0;
-            }
+            for (int q = 0; q < kFixMaxSrc; ++q) c[q] = (fixlane && q < ns) ? ft.C[i * ns + min(q, ns - 1)] : 0.0;
         };
         load_fix(0);
-        double Jn_[TC], In_[TC], Sn_[TC];
+        // Three register buffers rotate through the roles {being computed, next, after next}.  The
+        // rotation is unrolled (no register copies): copying a buffer whose loads are still in
+        // flight would force a wait on the newest loads and serialise the pipeline.
+        double J0[TC], I0[TC], E0[TC], S0[TC], J1[TC], I1[TC], E1[TC], S1[TC], J2[TC], I2[TC], E2[TC], S2[TC];
 #pragma unroll
-        for (int u = 0; u < TC; ++u) Sn_[u] = 0.0;
-        auto prefetch = [&](int t0) {
+        for (int u = 0; u < TC; ++u) {
+            S0[u] = S1[u] = S2[u] = 0; E0[u] = E1[u] = E2[u] = 0; I0[u] = I1[u] = I2[u] = 0;
+        }
+        int tp = 0, zp = 0;                                          // prefetch cursor
+        // Always issues the same number of loads (rows are clamped past the end): the wait counters the
+        // compiler derives are then exact and leave the younger chunk in flight.  The masked loads of the
+        // small-mu lanes (values written by k_smallmu) go first so that they never are the youngest.
+        auto fetch = [&](double (&Jx)[TC], double (&Ix)[TC], double (&Ex)[TC], double (&Sx)[TC]) {
+            const int tq = min(tp, L - 1);
+            if (small) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) Sx[u] = In[(size_t)min(tq + u, L - 1) * D + m];
+            }
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
-                const int t = min(t0 + u, L - 1);
-                Jn_[u] = J[(size_t)t * D + m];
-                In_[u] = ACC ? Iacc[(size_t)t * D + m] : 0.0;
+                const size_t row = (size_t)min(tq + u, L - 1) * D;
+                Jx[u] = (J + row)[m];
+                if (ACC) Ix[u] = (Iacc + row)[m];
+                if (ETAB) Ex[u] = (Et + row)[m];
             }
-            if (small) {                                            // one masked region: values written by k_smallmu
-#pragma unroll
-                for (int u = 0; u < TC; ++u) Sn_[u] = In[(size_t)min(t0 + u, L - 1) * D + m];
+            if (tp < L) {
+                int len = d.r1[zp] - tp + 1;
+                if (len > TC) len = TC;
+                tp += len;
+                if (tp > d.r1[zp] && zp + 1 < d.nz) ++zp;
             }
         };
-        prefetch(0);
-        for (int t0 = 0; t0 < L;) {
+        int t0 = 0;
+        auto process = [&](double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC], double (&Sc)[TC]) {
             if (t0 > d.r1[z]) { ++z; load_fix(z); }
             int len = d.r1[z] - t0 + 1;
             if (len > TC) len = TC;
-            double Jc[TC], Ic[TC], Sc[TC], E[TC], cc[TC], v[TC];
-#pragma unroll
-            for (int u = 0; u < TC; ++u) { Jc[u] = Jn_[u]; Ic[u] = In_[u]; Sc[u] = Sn_[u]; }
-            prefetch(min(t0 + len, L - 1));
+            double E[TC], cc[TC], v[TC];
             // independent part: attenuation and source term of every row of the chunk
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
                 const int t = min(t0 + u, L - 1);
                 const double dl = s_tau[t] - s_tau[max(t - 1, 0)];   // 0 at t = 0: E = 1, source 0
                 const double Jp = u == 0 ? Jprev : Jc[u - 1];
-                E[u] = exp(dl * rmu);
+                E[u] = ETAB ? Ec[u] : exp(dl * rmu);
                 cc[u] = -(dl * 0.5) * (Jp * E[u] + Jc[u]) * rmu;
             }
             // sequential part
@@ -593,11 +618,11 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
             if (valid) {
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
-                    const int t = t0 + u;
+                    const size_t row = (size_t)(t0 + u) * D;
                     if (u < len) {
-                        In[(size_t)t * D + m] = v[u];
-                        if (ACC) Iacc[(size_t)t * D + m] = Ic[u] + v[u];
-                        if (SAVED) sv[(size_t)t * D + m] = v[u];
+                        (In + row)[m] = v[u];
+                        if (ACC) (Iacc + row)[m] = Ic[u] + v[u];
+                        if (SAVED) (sv + row)[m] = v[u];
                     }
                 }
             }
@@ -612,6 +637,16 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
             if (t0 + len == L) { s_sfc[tid] = vlast; rdn_v = vlast; rdn_i = Ilast; }
             if (t0 + len - 1 == d.r1[z]) Dv = vlast;        // the next zone starts from the final row (spec:359,378)
             t0 += len;
+        };
+        fetch(J0, I0, E0, S0);
+        fetch(J1, I1, E1, S1);
+        for (;;) {
+            if (t0 >= L) break;
+            fetch(J2, I2, E2, S2); process(J0, I0, E0, S0);
+            if (t0 >= L) break;
+            fetch(J0, I0, E0, S0); process(J1, I1, E1, S1);
+            if (t0 >= L) break;
+            fetch(J1, I1, E1, S1); process(J2, I2, E2, S2);
         }
     }
     __syncthreads();
@@ -641,31 +676,39 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
         const double rmu = 1.0 / mu;
         double U = Bv, Jnext = 0;
         int z = d.nz - 1;
-        double Jn_[TC], In_[TC];
-        auto prefetch = [&](int t0) {
+        double J0[TC], I0[TC], E0[TC], J1[TC], I1[TC], E1[TC], J2[TC], I2[TC], E2[TC];
+#pragma unroll
+        for (int u = 0; u < TC; ++u) { E0[u] = E1[u] = E2[u] = 0; I0[u] = I1[u] = I2[u] = 0; }
+        int tp = L - 1, zp = d.nz - 1;
+        auto fetch = [&](double (&Jx)[TC], double (&Ix)[TC], double (&Ex)[TC]) {
+            const int tq = max(tp, 0);
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
-                const int t = max(t0 - u, 0);
-                Jn_[u] = J[(size_t)t * D + N + j];
-                In_[u] = ACC ? Iacc[(size_t)t * D + N + j] : 0.0;
+                const size_t row = (size_t)max(tq - u, 0) * D + N;
+                Jx[u] = (J + row)[j];
+                if (ACC) Ix[u] = (Iacc + row)[j];
+                if (ETAB) Ex[u] = (Et + row)[j];
+            }
+            if (tp >= 0) {
+                int len = tp - d.r0[zp] + 1;
+                if (len > TC) len = TC;
+                tp -= len;
+                if (tp < d.r0[zp] && zp > 0) --zp;
             }
         };
-        prefetch(L - 1);
-        for (int t0 = L - 1; t0 >= 0;) {
+        int t0 = L - 1;
+        auto process = [&](double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) {
             if (t0 < d.r0[z]) --z;
             int len = t0 - d.r0[z] + 1;
             if (len > TC) len = TC;
             const int zr1 = d.r1[z];
-            double Jc[TC], Ic[TC], E[TC], cc[TC], v[TC];
-#pragma unroll
-            for (int u = 0; u < TC; ++u) { Jc[u] = Jn_[u]; Ic[u] = In_[u]; }
-            prefetch(max(t0 - len, 0));
+            double E[TC], cc[TC], v[TC];
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
                 const int t = max(t0 - u, 0);
                 const double dl = s_tau[min(t + 1, L - 1)] - s_tau[t];   // 0 at t = L-1: E = 1, source 0
                 const double Jx = u == 0 ? Jnext : Jc[u - 1];
-                E[u] = exp(-dl * rmu);
+                E[u] = ETAB ? Ec[u] : exp(-dl * rmu);
                 // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
                 const double src = (dl * 0.5) * (Jc[u] + Jx * E[u]) * rmu;
                 cc[u] = (t == zr1) ? 0.0 : src;
@@ -710,15 +753,15 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
                     v[u] = (tr && tid < kf) ? bl : v[u];
                 }
             }
-            if (status != SOSRT_COL_OK) break;
+            if (status != SOSRT_COL_OK) { t0 = -1; return; }
             if (valid) {
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
-                    const int t = t0 - u;
+                    const size_t row = (size_t)max(t0 - u, 0) * D + N;
                     if (u < len) {
-                        In[(size_t)t * D + N + j] = v[u];
-                        if (ACC) Iacc[(size_t)t * D + N + j] = Ic[u] + v[u];
-                        if (SAVED) sv[(size_t)t * D + N + j] = v[u];
+                        (In + row)[j] = v[u];
+                        if (ACC) (Iacc + row)[j] = Ic[u] + v[u];
+                        if (SAVED) (sv + row)[j] = v[u];
                     }
                 }
             }
@@ -733,6 +776,16 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
             if (t0 - len + 1 == 0) { rup_v = vlast; rup_i = Ilast; }
             if (t0 - len + 1 == d.r0[z] && z > 0 && tr) U = vlast;       // blended row feeds the zone above
             t0 -= len;
+        };
+        fetch(J0, I0, E0);
+        fetch(J1, I1, E1);
+        for (;;) {
+            if (t0 < 0) break;
+            fetch(J2, I2, E2); process(J0, I0, E0);
+            if (t0 < 0) break;
+            fetch(J0, I0, E0); process(J1, I1, E1);
+            if (t0 < 0) break;
+            fetch(J1, I1, E1); process(J2, I2, E2);
         }
     }
     if (status != SOSRT_COL_OK) {
@@ -763,22 +816,54 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     }
 }
 
+// attenuation table of a column: E[t][m] = exp((tau_t - tau_{t-1}) / mu_m) for the downward lanes,
+// exp(-(tau_{t+1} - tau_t) / mu_m) for the upward ones; 0 for lanes that are not transported.
+__global__ void k_attenuation(Grid g, int B, const double* __restrict__ tau_all, double* __restrict__ E_all) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t LD = (size_t)g.L * g.D;
+    if (i >= (size_t)B * LD) return;
+    const int b = (int)(i / LD), t = (int)((i % LD) / g.D), m = (int)(i % g.D);
+    const double* tau = tau_all + (size_t)b * g.L;
+    const double mu = g.mu[m];
+    double E = 0;
+    if (m < g.N) {
+        const bool stdl = m <= g.N - 2 && !(fabs(mu) < kMuThreshold);
+        const double dl = tau[t] - tau[max(t - 1, 0)];
+        if (stdl) E = exp(dl * (1.0 / mu));
+    } else {
+        const double dl = tau[min(t + 1, g.L - 1)] - tau[t];
+        if (m > g.N) E = exp(-dl * (1.0 / mu));
+    }
+    E_all[i] = E;
+}
+
+void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab) {
+    const size_t n = (size_t)B * g.L * g.D;
+    hipLaunchKernelGGL(k_attenuation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, B, tau, Etab);
+}
+
 template <int MAXT>
 static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm, const TransportArgs& a) {
     if (a.accumulate) {
-        if (a.saved) hipLaunchKernelGGL((k_transport<MAXT, true, true>), grid, block, shm, s, a);
-        else hipLaunchKernelGGL((k_transport<MAXT, true, false>), grid, block, shm, s, a);
+        if (a.Etab) {
+            if (a.saved) hipLaunchKernelGGL((k_transport<MAXT, true, true, true>), grid, block, shm, s, a);
+            else hipLaunchKernelGGL((k_transport<MAXT, true, false, true>), grid, block, shm, s, a);
+        } else {
+            if (a.saved) hipLaunchKernelGGL((k_transport<MAXT, true, true, false>), grid, block, shm, s, a);
+            else hipLaunchKernelGGL((k_transport<MAXT, true, false, false>), grid, block, shm, s, a);
+        }
     } else {
-        hipLaunchKernelGGL((k_transport<MAXT, false, false>), grid, block, shm, s, a);
+        hipLaunchKernelGGL((k_transport<MAXT, false, false, false>), grid, block, shm, s, a);
     }
 }
 
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order,
-                      int accumulate) {
+                      int accumulate, const double* Etab) {
     const int nt = round64(g.N);
     const size_t shm = (size_t)(g.L + 2 * TC * (nt + 2) + 2 * nt + nt / 64 + 2) * sizeof(double);
-    TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate};
+    TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate,
+                    accumulate ? Etab : nullptr};
     // the register budget follows the workgroup size: one column needs few waves, so they may be fat
     if (nt <= 128) launch_transport_t<128>(s, dim3(B), dim3(nt), shm, a);
     else if (nt <= 256) launch_transport_t<256>(s, dim3(B), dim3(nt), shm, a);

@@ -78,7 +78,9 @@ void launch_gemm(hipStream_t s, const Grid& g, const double* A, const double* W,
 void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
-                      double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate);
+                      double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
+                      const double* Etab);
+void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab);
 void launch_fluxes(hipStream_t s, const Grid& g, int B, const double* tau, const double* I, const ColDesc* desc,
                    int beam_norm, double* fdn, double* fup);
 void launch_limit_rows(hipStream_t s, const Grid& g, int R, int table, const double* rows, double* out);
