@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--layers", type=int, default=200)
     ap.add_argument("--angles", type=int, default=128)
     ap.add_argument("--max-orders", type=int, default=256)
+    ap.add_argument("--inflight", type=int, default=1, help="independent solves in flight (own handle + stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -105,29 +106,61 @@ def main():
     w = build_sweep(a.columns, a.layers, a.angles, rank, world)
     B, L, N = w["B"], w["L"], w["N"]
     D = 2 * N
-    s = Solver(L, N, max_batch=B, max_orders=a.max_orders, device=local_rank)
-    stream = torch.cuda.current_stream(dev)
-    s.set_stream(stream.cuda_stream)
-    s.set_grid(w["mu"])
-    s.set_phase(w["P_atm"], w["P_aer"])
-    s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
-                  w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
     d_tau = torch.from_numpy(w["tau"]).to(dev)
     d_P0a = torch.from_numpy(w["P0a"]).to(dev)
     d_P0r = torch.from_numpy(w["P0r"]).to(dev)
-    d_I = torch.empty((B, L, D), dtype=torch.float64, device=dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    digest_bufs = None
 
-    def step():
-        s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), tol=1e-4,
-                       d_n_orders=d_n.data_ptr(), d_status=d_st.data_ptr())
-        if world > 1:
-            # the only collective: gather of the per-column digests to rank 0
-            dig = torch.cat([d_I[:, 0, N:], d_I[:, L - 1, :N], d_n.to(torch.float64)[:, None]], dim=1).contiguous()
-            bufs = [torch.empty_like(dig) for _ in range(world)] if rank == 0 else None
-            dist.gather(dig, bufs, dst=0)
+    # `inflight` independent solves may be in flight at once, each on its own handle and HIP stream:
+    # the order loop of a sweep ends in a long tail of launches over its few slowest-converging
+    # columns, which leaves most CUs idle; the next sweep's dense launches fill them.
+    class Lane:
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device=dev)
+            self.s = Solver(L, N, max_batch=B, max_orders=a.max_orders, device=local_rank)
+            self.s.set_stream(self.stream.cuda_stream)
+            self.s.set_grid(w["mu"])
+            self.s.set_phase(w["P_atm"], w["P_aer"])
+            self.s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
+                               w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
+            self.I = torch.empty((B, L, D), dtype=torch.float64, device=dev)
+            self.n = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.st = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.done = torch.cuda.Event()
+
+        def solve(self):
+            """Enqueue one step on this lane's stream; returns (digest tensor or None, completion event)."""
+            self.s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), self.I.data_ptr(), tol=1e-4,
+                                d_n_orders=self.n.data_ptr(), d_status=self.st.data_ptr())
+            dig = None
+            if world > 1:
+                with torch.cuda.stream(self.stream):
+                    dig = torch.cat([self.I[:, 0, N:], self.I[:, L - 1, :N], self.n.to(torch.float64)[:, None]], dim=1).contiguous()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            return dig, ev
+
+    torch.cuda.synchronize(dev)
+    lanes = [Lane() for _ in range(max(1, a.inflight))]
+    main_stream = torch.cuda.current_stream(dev)
+
+    from concurrent.futures import ThreadPoolExecutor
+    execs = [ThreadPoolExecutor(max_workers=1) for _ in lanes]       # a lane runs its steps in order
+
+    def lane_step(i):
+        torch.cuda.set_device(local_rank)
+        return lanes[i].solve()
+
+    def run_steps(k):
+        """k steps dealt round-robin to the lanes.  With several ranks the per-column digests (TOA-up row,
+        surface-down row, order count) of every step are gathered to rank 0 -- the only collective --
+        from this thread, in step order, behind the step's completion event."""
+        futs = [execs[step % len(lanes)].submit(lane_step, step % len(lanes)) for step in range(k)]
+        for f in futs:
+            dig, ev = f.result()
+            if world > 1:
+                main_stream.wait_event(ev)
+                bufs = [torch.empty_like(dig) for _ in range(world)] if rank == 0 else None
+                dist.gather(dig, bufs, dst=0)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -135,25 +168,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
+    run_steps(a.warmup)
     sync_all()
-    s.profile_enable(True)
-    s.profile_reset()
-    sum_orders = 0
+    for ln in lanes:
+        ln.s.profile_enable(True)
+        ln.s.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        sum_orders += 0      # orders are read back after the timed region (same every step)
+    run_steps(a.steps)
     sync_all()
     dt = time.perf_counter() - t0
-    n_host = d_n.cpu().numpy()
-    st_host = d_st.cpu().numpy()
+    n_host = lanes[0].n.cpu().numpy()
+    st_host = lanes[0].st.cpu().numpy()
     orders_per_step = int((n_host - 1).sum())
-    gemm_ms, gemm_launches = s.profile_get(_lib.K_GEMM)
-    tr_ms, tr_launches = s.profile_get(_lib.K_TRANSPORT)
-    fo_ms, _ = s.profile_get(_lib.K_FIRST)
-    s.profile_enable(False)
+    gemm_ms = tr_ms = fo_ms = 0.0
+    gemm_launches = 0
+    for ln in lanes:
+        ms, cnt = ln.s.profile_get(_lib.K_GEMM); gemm_ms += ms; gemm_launches += cnt
+        tr_ms += ln.s.profile_get(_lib.K_TRANSPORT)[0]
+        fo_ms += ln.s.profile_get(_lib.K_FIRST)[0]
+        ln.s.profile_enable(False)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -175,7 +208,8 @@ def main():
             "config": {"workload": "C4 sweep: %d columns/GPU = mu0 x tau*_aer x grd_alb grid, L=%d, N=%d (D=%d), "
                                    "Rayleigh atm + HG(0.7) aerosol stand-in, specular surface, tol 1e-4" % (B, L, N, D),
                        "columns_per_gpu": B, "orders_per_step": orders_per_step, "max_order": int(n_host.max()),
-                       "not_converged": int((st_host != 0).sum()), "parallelism": "columns sharded x%d, gather only" % world},
+                       "not_converged": int((st_host != 0).sum()), "inflight_solves": len(lanes),
+                       "parallelism": "columns sharded x%d, gather only" % world},
             "roofline": {"bound": "mfma", "kernel": "k_jn_gemm", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": gemm_ms / max(gemm_launches, 1), "launches": gemm_launches},
