@@ -72,7 +72,9 @@ struct sosrt_handle {
     double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr, *d_E = nullptr;
     int use_etab = 1;
     // convergence
-    int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr;
+    int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr;
+    int transport_mode = 1;              // 1: wave-independent fast kernel (+ repair), 0: general kernel
+    bool fast_ok = false;
     double* d_ratio = nullptr;
     int* h_poll = nullptr;               // pinned [2]
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
@@ -114,7 +116,7 @@ int need_gpu(sosrt_handle* h) {
 Conv make_conv(sosrt_handle* h, double tol) {
     Conv c;
     c.active = h->d_active; c.norders = h->d_norders; c.status = h->d_status;
-    c.nactive = h->d_nactive; c.ratio = h->d_ratio; c.tol = tol;
+    c.nactive = h->d_nactive; c.ratio = h->d_ratio; c.tol = tol; c.redo = h->d_redo;
     return c;
 }
 
@@ -168,6 +170,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;
     h->gpu = device >= 0;
     if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
+    if (const char* ev = getenv("SOSRT_TRANSPORT")) h->transport_mode = (strcmp(ev, "general") == 0) ? 0 : 1;
     Grid& g = h->g;
     g.L = L; g.N = N; g.D = 2 * N;
     g.Dp = (g.D + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
@@ -205,6 +208,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_norders, mb))) return e;
             if ((e = dalloc(&h->d_status, mb))) return e;
             if ((e = dalloc(&h->d_nactive, 1))) return e;
+            if ((e = dalloc(&h->d_redo, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
             HIPCHK(hipHostMalloc((void**)&h->h_poll, 2 * sizeof(int), hipHostMallocDefault));
             HIPCHK(hipEventCreateWithFlags(&h->poll_ev[0], hipEventDisableTiming));
@@ -212,6 +216,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             HIPCHK(hipMemset(h->d_Wa, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
             HIPCHK(hipMemset(h->d_Wr, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
             HIPCHK(hipMemset(h->d_status, 0, mb * sizeof(int)));
+            HIPCHK(hipMemset(h->d_redo, 0, mb * sizeof(int)));
             HIPCHK(hipMemset(h->d_tau, 0, mb * L * sizeof(double)));
             return 0;
         };
@@ -231,7 +236,7 @@ int sosrt_destroy(sosrt_t* h) {
         void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
-                        h->d_nactive, h->d_ratio};
+                        h->d_nactive, h->d_ratio, h->d_redo};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_poll) hipHostFree(h->h_poll);
@@ -269,6 +274,7 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
         if (h->plan.fix[b].idx > kFixMaxIdx) return fail(SOSRT_E_INVALID, "nb_angles too large for the extrapolation tables");
     h->have_grid = true;
     h->have_phase = false;
+    h->fast_ok = transport_fast_ok(h->plan);
     if (h->gpu) {
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipMemcpy(h->d_mu, mu, h->D * sizeof(double), hipMemcpyHostToDevice));
@@ -412,7 +418,15 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     launch_smallmu(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, h->d_desc, nullptr);
     prof_end(h, SOSRT_K_SMALLMU);
     prof_begin(h, SOSRT_K_TRANSPORT);
-    launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, nullptr);
+    if (h->transport_mode == 1 && h->fast_ok) {
+        launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E);
+        HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
+        launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 1);
+        if (h->N - 3 > 61)
+            launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 2);
+    } else {
+        launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, nullptr, 0);
+    }
     prof_end(h, SOSRT_K_TRANSPORT);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(In_out, h->d_InB, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -467,7 +481,9 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
 
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr);
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
-    if (h->use_etab) launch_attenuation(s, g, B, d_tau, h->d_E);
+    const bool fast = h->transport_mode == 1 && h->fast_ok;
+    if (h->use_etab || fast) launch_attenuation(s, g, B, d_tau, h->d_E);
+    if (fast) HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), s));
     double* In_1 = h->d_InA;
     double* In = h->d_InB;
     prof_begin(h, SOSRT_K_FIRST);
@@ -499,9 +515,15 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             prof_end(h, SOSRT_K_SMALLMU);
         }
         prof_begin(h, SOSRT_K_TRANSPORT);
-        launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out,
-                         d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr, saved_stride, h->d_desc, cv, n, 1,
-                         h->use_etab ? h->d_E : nullptr);
+        double* sv_n = d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr;
+        if (fast) {
+            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 1);
+            if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
+                launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 2);
+        } else {
+            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1,
+                             h->use_etab ? h->d_E : nullptr, 0);
+        }
         prof_end(h, SOSRT_K_TRANSPORT);
         HIPCHK(hipMemcpyAsync(&h->h_poll[n & 1], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipEventRecord(h->poll_ev[n & 1], s));

@@ -63,6 +63,7 @@ struct Conv {
     int* status;               // [B]
     int* nactive;              // [1]
     double* ratio;             // [B] last value of the spec:309 test
+    int* redo;                 // [B] set by k_transport_fast when the column needs the general upward sweep
     double tol;
 };
 
@@ -79,7 +80,8 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
-                      const double* Etab);
+                      const double* Etab, int mode);
+bool transport_fast_ok(const Plan& plan);
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab);
 void launch_fluxes(hipStream_t s, const Grid& g, int B, const double* tau, const double* I, const ColDesc* desc,
                    int beam_norm, double* fdn, double* fup);

@@ -54,7 +54,8 @@ _solvers = {}
 
 
 def get_solver(nb_layers, nb_angles, batch, max_orders, device=0) -> Solver:
-    key = (nb_layers, nb_angles, device)
+    import os
+    key = (nb_layers, nb_angles, device, os.environ.get("SOSRT_TRANSPORT", ""))
     s = _solvers.get(key)
     if s is None or s.max_batch < batch or s.max_orders < max_orders:
         if s is not None:

@@ -16,6 +16,19 @@ from util import RTOL, assert_close, column_case, g1_case, golden, oracle_column
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["fast", "general"])
+def transport_mode(request, monkeypatch):
+    """Both transport kernels: the wave-independent one (+ repair) and the general LDS-exchange one."""
+    monkeypatch.setenv("SOSRT_TRANSPORT", request.param)
+    for s in list(I1_In._handles.values()):
+        s.close()
+    I1_In._handles.clear()
+    yield request.param
+    for s in list(I1_In._handles.values()):
+        s.close()
+    I1_In._handles.clear()
+
+
 # ----------------------------------------------------------------------------------------------
 # MFMA contraction: operand / result lane maps, with asymmetric data
 # ----------------------------------------------------------------------------------------------
@@ -41,7 +54,7 @@ def test_source_function_is_the_dense_product(L, N, B):
 # step level against the reference's own outputs (G1): every a4a / a4b branch
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("path", golden("g1_*.npz"), ids=lambda p: p.split("/")[-1][3:-4])
-def test_step_functions_match_reference(path):
+def test_step_functions_match_reference(path, transport_mode):
     d, N, P = g1_case(path)
     tau, mu, tS, mu0, alb = d["tau"], d["mu"], float(d["tauStar"]), float(d["mu0"]), float(d["alb"])
     assert_close(I1_In.I1_NumInt(tau, mu, tS, mu0, d["P0"], alb, N), d["I1"], RTOL, "I1_NumInt")
@@ -73,6 +86,25 @@ def test_helpers_match_reference():
         assert In_limit.mu_approx_In(inputs.direction_grid(int(N)), int(N)) == (int(m1), int(m2))
 
 
+def test_search_beyond_wave0_is_repaired(transport_mode):
+    """Second differences above 1e-4 over the first ~70 upward angles: the search leaves wave 0 and the
+    fast kernel hands the column to the general one (cv.redo); same numbers as the oracle either way."""
+    N, L = 128, 24
+    mu = inputs.direction_grid(N)
+    tau = np.linspace(0, 0.4, L) ** 1.3
+    j = np.arange(N)
+    Jn = np.zeros((L, 2 * N))
+    Jn[:, :N] = 0.03 + 0.01 * np.linspace(0, 1, N)
+    Jn[:, N:] = 0.1 * (1.0 + 0.3 * mu[N:])[None, :] * (1 + 0.2 * np.linspace(0, 1, L))[:, None]
+    Jn[:, N:] += np.where(j < 70, 0.02 * (-1.0) ** j, 0.0)[None, :]
+    ref = O.In_NumInt(2, Jn, None, tau, mu, 0.4, 0.5, None, 1.0, N, literal=False)
+    got = I1_In.In_NumInt(2, Jn, None, tau, mu, 0.4, 0.5, np.ones((2 * N, 2 * N)), 1.0, N, 0, 0)
+    assert_close(got, ref, RTOL, "In with a long blend")
+    # the blend really reaches beyond lane 63: the row is exactly linear in mu up to lane ~70
+    d2 = np.abs(np.diff(ref[L // 2, N:], 2))
+    assert int(np.argmax(d2 > 1e-12)) + 1 > 64
+
+
 def test_index_error_like_the_reference():
     N, L = 16, 6
     mu = inputs.direction_grid(N)
@@ -101,7 +133,7 @@ def _solve_fixture(c, I1=None, max_orders=64):
 
 
 @pytest.mark.parametrize("path", golden("g3_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
-def test_specular_column_matches_reference(path):
+def test_specular_column_matches_reference(path, transport_mode):
     d, c = column_case(path)
     r, fd, fu = _solve_fixture(c)
     assert r.status[0] == _lib.COL_OK and r.n[0] == c["n"]
@@ -115,7 +147,7 @@ def test_specular_column_matches_reference(path):
 
 
 @pytest.mark.parametrize("path", golden("g6_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
-def test_lambertian_orders_match_modified_reference(path):
+def test_lambertian_orders_match_modified_reference(path, transport_mode):
     """n >= 2 with the coded sign of lam:399/401, seeded with the fixture's first order (H1, H2)."""
     d, c = column_case(path)
     r, _, _ = _solve_fixture(c, I1=d["I_saved"][0])
@@ -157,7 +189,7 @@ def test_SOS_Aer_call_surface():
 # seeded batches against the oracle (ragged convergence, every surface, every idx bucket)
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("L,N,surface", [(40, 32, "specular"), (36, 64, "lambertian"), (30, 100, "specular")])
-def test_seeded_batch_matches_oracle(L, N, surface):
+def test_seeded_batch_matches_oracle(L, N, surface, transport_mode):
     rng = np.random.default_rng(1000 + N)
     B = 6
     mu0 = rng.uniform(0.2, 1.0, B)
