@@ -145,6 +145,10 @@ int sosrt_profile_reset(sosrt_t* h);
 /* total milliseconds and launch count since the last reset (synchronises the stream) */
 int sosrt_profile_get(sosrt_t* h, int kernel, double* total_ms, long long* launches, double* work /*flops or bytes*/);
 
+/* ---- diagnostics: device buffer [B][2][8] of clock64() stamps written by the fast transport kernel
+ * (start, prologue done, downward done, surface done, upward done, end); NULL switches it off */
+int sosrt_debug_stamps(sosrt_t* h, unsigned long long* d_stamps);
+
 /* ---- machine peaks measured on this device (roofline denominators) --------------------------- */
 /* which 0: back-to-back v_mfma_f64_16x16x4_f64, TFLOP/s; 1: streaming copy of 1 GiB, GB/s (read+write);
  * 2: v_fma_f64, TFLOP/s. */

@@ -689,6 +689,15 @@ int sosrt_plan_fix_table(sosrt_t* h, int idx, int* s0, int* ns, double* C_out) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// diagnostics: cycle stamps of k_transport_fast ([B][2 waves][8] clock64 values; pass NULL to stop)
+// ---------------------------------------------------------------------------------------------
+int sosrt_debug_stamps(sosrt_t* h, unsigned long long* d_stamps) {
+    if (int e = need_gpu(h)) return e;
+    sosrt::g_transport_stamps = d_stamps;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // machine peaks
 // ---------------------------------------------------------------------------------------------
 int sosrt_microbench(sosrt_t* h, int which, double* result) {

@@ -457,28 +457,6 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
 // directions: the extrapolation of the last downward angles (In_limit:113-141, here a fixed
 // linear map) and the upward second-difference search and blend (spec:402-409).
 // ------------------------------------------------------------------------------------------
-// Rows are processed in chunks of TC: the loads of the next chunk are in flight while the current
-// one is computed, the TC exponentials of a chunk are independent (instruction-level parallelism
-// for the one wave per SIMD a column gives), only the TC fused multiply-adds of the recurrence are
-// sequential, and the workgroup meets once per chunk to exchange rows.  A chunk never crosses a
-// zone boundary, because the next zone restarts from the final (rewritten / blended) row.
-constexpr int TC = 8;
-
-struct TransportArgs {
-    Grid g;
-    const double* tau;
-    const double* Jn;
-    double* In;
-    double* I;
-    double* saved;
-    size_t saved_col_stride;
-    const ColDesc* desc;
-    Conv cv;
-    int order;
-    int accumulate;
-    const double* Etab;
-};
-
 // The chunk loops are written branch-free (clamped row indices, selects instead of predicated
 // blocks, reciprocal of mu hoisted) so that the compiler can interleave the TC independent
 // chains of a chunk: with one wave per SIMD, instruction-level parallelism is the only latency
@@ -828,294 +806,6 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// k_transport_fast: the same order of transport with wave-independent sweeps.
-//
-// Thread j carries the downward direction m = N-1-j and the upward direction m = N+j, so both
-// mu -> 0 neighbourhoods live in the first lanes of wave 0: the extrapolated downward angles and
-// their source angles (In_limit:113-141) are lanes < idx + n_src, the upward second-difference
-// search (spec:403-406) almost always ends within the first lanes, and the specular mirror of an
-// upward direction (spec:397) is the thread's own downward direction.  Wave 0 resolves both
-// treatments with cross-lane reads; the other waves are pure recurrences.  No LDS exchange and no
-// barrier inside the sweeps.  If a search does not end within wave 0 (or the extrapolation does
-// not fit in it) the column is flagged in cv.redo and k_transport<.., REPAIR> recomputes its upward
-// sweep with the general exchange; results are the same numbers.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_f64(double v, int srclane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, srclane);
-    hi = __builtin_amdgcn_readlane(hi, srclane);
-    return __hiloint2double(hi, lo);
-}
-
-template <int MAXT, bool ACC, bool SAVED>
-__global__ __launch_bounds__(MAXT) void k_transport_fast(TransportArgs a) {
-    const int b = blockIdx.x;
-    if (ACC && !a.cv.active[b]) return;
-    const Grid& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = g.L, N = g.N, D = g.D;
-    extern __shared__ double sm[];
-    double* s_sfc = sm;                      // [blockDim] surface row by downward lane m
-    double* s_red = s_sfc + blockDim.x;      // [nw + 1]
-    __shared__ FixTab s_fix[kMaxZones];
-    __shared__ int s_flag[2];                // [0] redo with the general kernel, [1] IndexError
-    const ColDesc* __restrict__ dg = a.desc + b;     // uniform address: scalar loads
-    const int nz = dg->nz;
-    const int zend0 = nz > 1 ? dg->r1[0] : -1, zend1 = nz > 2 ? dg->r1[1] : -1;       // last rows of the non-bottom zones
-    const int zbeg1 = nz > 1 ? dg->r0[1] : -1, zbeg2 = nz > 2 ? dg->r0[2] : -1;       // first rows of the non-top zones
-    const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
-    const int surface = dg->surface;
-    const double rho = dg->rho;
-    for (int zz = 0; zz < kMaxZones; ++zz) {
-        const double* src = reinterpret_cast<const double*>(&g.fix[dg->fixtab[zz]]);
-        double* dst = reinterpret_cast<double*>(&s_fix[zz]);
-        for (int i = tid; i < (int)(sizeof(FixTab) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
-    }
-    if (tid < 2) s_flag[tid] = 0;
-    const double* __restrict__ tau = a.tau + (size_t)b * L;
-    const double* __restrict__ J = a.Jn + (size_t)b * L * D;
-    const double* __restrict__ Et = a.Etab + (size_t)b * L * D;
-    double* __restrict__ In = a.In + (size_t)b * L * D;
-    double* __restrict__ Iacc = ACC ? a.I + (size_t)b * L * D : nullptr;
-    double* __restrict__ sv = SAVED ? a.saved + (size_t)b * a.saved_col_stride : nullptr;
-    __syncthreads();
-
-    const bool valid = tid < N;
-    const int tidc = valid ? tid : N - 1;
-    double rdn_v = 0, rdn_i = 1, rup_v = 0, rup_i = 1;
-    double sfc_own = 0;                      // In[L-1][N-1-tid]
-
-    // =============================== downward ===============================
-    {
-        const int m = N - 1 - tidc;
-        const double mu = g.mu[m];
-        const bool tr = valid && m <= N - 2;
-        const bool small = tr && fabs(mu) < kMuThreshold;       // spec:333
-        const bool stdl = tr && !small;
-        const double rmu = 1.0 / (stdl ? mu : -1.0);
-        double Dv = 0, Jprev = 0;
-        double c[kFixMaxSrc] = {0, 0, 0, 0, 0};
-        int nfx = 0, srcbase = 0;
-        bool fixlane = false;
-        auto load_fix = [&](int zz) {                          // wave 0 only; lane i < idx owns row i of the table
-            const FixTab& ft = s_fix[zz];
-            nfx = zz == 0 ? nfix0 : (zz == 1 ? nfix1 : nfix2);
-            const int ns = ft.ns;
-            srcbase = nfx + ns - 1;                             // lane of source q is srcbase - q
-            fixlane = nfx > 0 && tid < nfx;
-            const int i = fixlane ? tid : 0;
-#pragma unroll
-            for (int q = 0; q < kFixMaxSrc; ++q) c[q] = (fixlane && q < ns) ? ft.C[i * ns + min(q, ns - 1)] : 0.0;
-        };
-        load_fix(0);
-        double J0[TC], I0[TC], E0[TC], S0[TC], J1[TC], I1[TC], E1[TC], S1[TC], J2[TC], I2[TC], E2[TC], S2[TC];
-#pragma unroll
-        for (int u = 0; u < TC; ++u) { S0[u] = S1[u] = S2[u] = 0; I0[u] = I1[u] = I2[u] = 0; }
-        int tp = 0;
-        auto fetch = [&](double (&Jx)[TC], double (&Ix)[TC], double (&Ex)[TC], double (&Sx)[TC]) {
-            const int tq = min(tp, L - 1);
-            if (small) {                                            // values written by k_smallmu
-#pragma unroll
-                for (int u = 0; u < TC; ++u) Sx[u] = In[(size_t)min(tq + u, L - 1) * D + m];
-            }
-#pragma unroll
-            for (int u = 0; u < TC; ++u) {
-                const size_t row = (size_t)min(tq + u, L - 1) * D;
-                Jx[u] = (J + row)[m];
-                if (ACC) Ix[u] = (Iacc + row)[m];
-                Ex[u] = (Et + row)[m];
-            }
-            tp += TC;
-        };
-        int t0 = 0;
-        auto process = [&](double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC], double (&Sc)[TC]) {
-            double cc[TC], v[TC];
-#pragma unroll
-            for (int u = 0; u < TC; ++u) {                         // independent: source term of every row
-                const int t = min(t0 + u, L - 1);
-                const double dl = tau[t] - tau[max(t - 1, 0)];     // uniform: scalar loads
-                const double Jp = u == 0 ? Jprev : Jc[u - 1];
-                cc[u] = -(dl * 0.5) * (Jp * Ec[u] + Jc[u]) * rmu;
-            }
-#pragma unroll
-            for (int u = 0; u < TC; ++u) {                         // sequential: the recurrence
-                const int t = t0 + u;
-                if (wave == 0 && (t == zbeg1 || t == zbeg2)) load_fix(t == zbeg1 ? 1 : 2);
-                const double Dn = Dv * Ec[u] + cc[u];
-                double x = stdl ? Dn : (small ? Sc[u] : 0.0);
-                if (wave == 0 && nfx > 0) {                        // In_limit:113-141 as a linear map of the source lanes
-                    double acc = 0;
-#pragma unroll
-                    for (int q = 0; q < kFixMaxSrc; ++q) acc += c[q] * readlane_f64(x, max(srcbase - q, 0));
-                    x = fixlane ? acc : x;
-                }
-                v[u] = x;
-                const bool zone_end = t == zend0 || t == zend1;     // the next zone starts from the final row (spec:359,378)
-                Dv = t < L ? (zone_end ? x : Dn) : Dv;
-            }
-            if (valid) {
-#pragma unroll
-                for (int u = 0; u < TC; ++u) {
-                    const int t = t0 + u;
-                    const size_t row = (size_t)t * D;
-                    if (t < L) {
-                        (In + row)[m] = v[u];
-                        if (ACC) (Iacc + row)[m] = Ic[u] + v[u];
-                        if (SAVED) (sv + row)[m] = v[u];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < TC; ++u)
-                if (t0 + u == L - 1) { sfc_own = v[u]; rdn_v = v[u]; rdn_i = Ic[u] + v[u]; }
-            Jprev = Jc[TC - 1];
-            t0 += TC;
-        };
-        fetch(J0, I0, E0, S0);
-        fetch(J1, I1, E1, S1);
-        for (;;) {
-            if (t0 >= L) break;
-            fetch(J2, I2, E2, S2); process(J0, I0, E0, S0);
-            if (t0 >= L) break;
-            fetch(J0, I0, E0, S0); process(J1, I1, E1, S1);
-            if (t0 >= L) break;
-            fetch(J1, I1, E1, S1); process(J2, I2, E2, S2);
-        }
-    }
-
-    // =============================== surface ===============================
-    double Bv = 0;
-    if (surface == SOSRT_SURFACE_SPECULAR) {
-        Bv = valid ? rho * sfc_own : 0.0;                           // spec:397: the mirror direction is this thread's own
-    } else if (surface == SOSRT_SURFACE_LAMBERTIAN) {
-        if (valid) s_sfc[N - 1 - tid] = sfc_own;
-        __syncthreads();
-        // -2 rho trapz(In[L-1, rev] mu[rev], mu[rev]), rev = N-2 .. 0   (lam:399), descending abscissae
-        double term = 0;
-        if (tid <= N - 3) {
-            const int k0 = N - 2 - tid, k1 = k0 - 1;
-            const double x0 = g.mu[k0], x1 = g.mu[k1];
-            term = (x1 - x0) * (s_sfc[k1] * x1 + s_sfc[k0] * x0) / 2;
-        }
-        const double S = block_sum(term, s_red);
-        Bv = -2 * rho * S;
-    }
-
-    // =============================== upward ===============================
-    {
-        const int j = tidc;
-        const bool tr = valid && tid > 0;
-        const double mu = tr ? g.mu[N + j] : 1.0;
-        const double rmu = 1.0 / mu;
-        const int last_cand = min(N - 3, 61);                      // lanes whose two right neighbours are in wave 0
-        double U = Bv, Jnext = 0;
-        double J0[TC], I0[TC], E0[TC], J1[TC], I1[TC], E1[TC], J2[TC], I2[TC], E2[TC];
-#pragma unroll
-        for (int u = 0; u < TC; ++u) { I0[u] = I1[u] = I2[u] = 0; }
-        int tp = L - 1;
-        auto fetch = [&](double (&Jx)[TC], double (&Ix)[TC], double (&Ex)[TC]) {
-            const int tq = max(tp, 0);
-#pragma unroll
-            for (int u = 0; u < TC; ++u) {
-                const size_t row = (size_t)max(tq - u, 0) * D + N;
-                Jx[u] = (J + row)[j];
-                if (ACC) Ix[u] = (Iacc + row)[j];
-                Ex[u] = (Et + row)[j];
-            }
-            tp -= TC;
-        };
-        int t0 = L - 1;
-        auto process = [&](double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) {
-            double cc[TC], v[TC];
-#pragma unroll
-            for (int u = 0; u < TC; ++u) {
-                const int t = max(t0 - u, 0);
-                const double dl = tau[min(t + 1, L - 1)] - tau[t];
-                const double Jx = u == 0 ? Jnext : Jc[u - 1];
-                const double src = (dl * 0.5) * (Jc[u] + Jx * Ec[u]) * rmu;
-                // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
-                cc[u] = (t == zend0 || t == zend1) ? 0.0 : src;
-            }
-#pragma unroll
-            for (int u = 0; u < TC; ++u) {
-                const int t = t0 - u;
-                const double Un = U * Ec[u] + cc[u];
-                double x = (tid == 0) ? Jc[u] : Un;                     // spec:401
-                if (wave == 0 && t >= 0) {                             // spec:403-409 within the wave
-                    const double x1 = __shfl_down(x, 1, 64), x2 = __shfl_down(x, 2, 64);
-                    const bool stop = lane >= 1 && lane <= last_cand && !(fabs((x - x1) - (x1 - x2)) > 0.0001);
-                    const unsigned long long mk = __ballot(stop);
-                    int kf = 1;
-                    if (mk) kf = __ffsll((long long)mk);                // ks + 1
-                    else if (lane == 0) s_flag[N - 3 <= 61 ? 1 : 0] = 1;   // IndexError in the reference / search leaves the wave
-                    const double r0 = readlane_f64(x, 0), rk = readlane_f64(x, kf);
-                    const double w = mu / readlane_f64(mu, kf);
-                    const double bl = (1 - w) * r0 + w * rk;
-                    x = (tr && tid < kf) ? bl : x;
-                }
-                v[u] = x;
-                const bool zone_start = t == zbeg1 || t == zbeg2;       // blended row feeds the zone above
-                U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
-            }
-            if (valid) {
-#pragma unroll
-                for (int u = 0; u < TC; ++u) {
-                    const int t = t0 - u;
-                    if (t >= 0) {
-                        const size_t row = (size_t)t * D + N;
-                        (In + row)[j] = v[u];
-                        if (ACC) (Iacc + row)[j] = Ic[u] + v[u];
-                        if (SAVED) (sv + row)[j] = v[u];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < TC; ++u)
-                if (t0 - u == 0) { rup_v = v[u]; rup_i = Ic[u] + v[u]; }
-            Jnext = Jc[TC - 1];
-            t0 -= TC;
-        };
-        fetch(J0, I0, E0);
-        fetch(J1, I1, E1);
-        for (;;) {
-            if (t0 < 0) break;
-            fetch(J2, I2, E2); process(J0, I0, E0);
-            if (t0 < 0) break;
-            fetch(J0, I0, E0); process(J1, I1, E1);
-            if (t0 < 0) break;
-            fetch(J1, I1, E1); process(J2, I2, E2);
-        }
-    }
-    __syncthreads();
-    if (s_flag[1]) {                                                    // the reference raises IndexError (spec:404)
-        if (tid == 0) {
-            a.cv.status[b] = SOSRT_COL_INDEXERROR;
-            if (ACC) { a.cv.active[b] = 0; a.cv.norders[b] = a.order; atomicSub(a.cv.nactive, 1); }
-        }
-        return;
-    }
-    if (s_flag[0]) {                                                    // let the general kernel redo the upward sweep
-        if (tid == 0) a.cv.redo[b] = 1;
-        return;
-    }
-    if (ACC) {
-        const double ra = block_pymax(rup_v / rup_i, valid, s_red, 0);
-        const double rb = block_pymax(rdn_v / rdn_i, valid, s_red, N - 1);   // m = 0 is thread N-1
-        const double r = outer_pymax(ra, rb);
-        if (tid == 0) {
-            a.cv.ratio[b] = r;
-            a.cv.norders[b] = a.order;
-            if (!(r >= a.cv.tol)) {
-                a.cv.active[b] = 0;
-                atomicSub(a.cv.nactive, 1);
-            }
-        }
-    } else if (tid == 0 && a.cv.status) {
-        a.cv.status[b] = SOSRT_COL_OK;
-    }
-}
-
 // attenuation table of a column: E[t][m] = exp((tau_t - tau_{t-1}) / mu_m) for the downward lanes,
 // exp(-(tau_{t+1} - tau_t) / mu_m) for the upward ones; 0 for lanes that are not transported.
 __global__ void k_attenuation(Grid g, int B, const double* __restrict__ tau_all, double* __restrict__ E_all) {
@@ -1146,12 +836,7 @@ template <int MAXT>
 static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm, const TransportArgs& a, int mode) {
     // mode 0: general kernel, 1: wave-independent fast kernel, 2: general kernel repairing flagged columns
     if (mode == 1) {
-        if (a.accumulate) {
-            if (a.saved) hipLaunchKernelGGL((k_transport_fast<MAXT, true, true>), grid, block, shm, s, a);
-            else hipLaunchKernelGGL((k_transport_fast<MAXT, true, false>), grid, block, shm, s, a);
-        } else {
-            hipLaunchKernelGGL((k_transport_fast<MAXT, false, false>), grid, block, shm, s, a);
-        }
+        launch_transport_fast(s, grid, block, a);
     } else if (mode == 2) {
         if (a.accumulate) {
             if (a.saved) hipLaunchKernelGGL((k_transport<MAXT, true, true, true, true>), grid, block, shm, s, a);
@@ -1173,10 +858,13 @@ static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm,
     }
 }
 
+unsigned long long* g_transport_stamps = nullptr;   // set by sosrt_debug_stamps (diagnostics)
+
 // True when both mu -> 0 treatments of a column fit in wave 0 of k_transport_fast.
 bool transport_fast_ok(const Plan& plan) {
+    // every rewritten downward direction and its source directions must sit in the last wave
     for (int bkt = 0; bkt < 4; ++bkt)
-        if (plan.fix[bkt].idx > 0 && plan.fix[bkt].idx + plan.fix[bkt].ns > 64) return false;
+        if (plan.fix[bkt].idx > 0 && (plan.fix[bkt].s0 >> 6) != ((plan.N - 1) >> 6)) return false;
     return true;
 }
 
@@ -1185,7 +873,7 @@ void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, co
                       int accumulate, const double* Etab, int mode) {
     const int nt = round64(g.N);
     const size_t shm = (size_t)(g.L + 2 * TC * (nt + 2) + 2 * nt + nt / 64 + 2) * sizeof(double);
-    TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab};
+    TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab, g_transport_stamps};
     // the register budget follows the workgroup size: one column needs few waves, so they may be fat
     if (nt <= 128) launch_transport_t<128>(s, dim3(B), dim3(nt), shm, a, mode);
     else if (nt <= 256) launch_transport_t<256>(s, dim3(B), dim3(nt), shm, a, mode);

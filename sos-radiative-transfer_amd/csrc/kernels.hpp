@@ -69,6 +69,30 @@ struct Conv {
 
 constexpr int GEMM_BM = 64, GEMM_BN = 128, GEMM_KC = 16;
 
+// Transport rows are processed in chunks of TC: the loads of the next chunks are in flight while
+// the current one is computed, the per-row source terms of a chunk are independent
+// (instruction-level parallelism for the one wave per SIMD a column gives), only the TC fused
+// multiply-adds of the recurrence are sequential.
+constexpr int TC = 8;
+
+struct TransportArgs {
+    Grid g;
+    const double* tau;
+    const double* Jn;
+    double* In;
+    double* I;
+    double* saved;
+    size_t saved_col_stride;
+    const ColDesc* desc;
+    Conv cv;
+    int order;
+    int accumulate;
+    const double* Etab;
+    unsigned long long* stamps;   // diagnostic builds only: [B][8] cycle stamps of the sweeps (nullable)
+};
+void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
+extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
+
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
                     ColDesc* desc, double* rowcoef_a, double* rowcoef_r);
 void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, const double* P0a, const double* P0r,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sosrt_plan_fold": (c_int, [c_void_p, c_int, c_void_p]),
     "sosrt_plan_fix_table": (c_int, [c_void_p, c_int, _ip, _ip, c_void_p]),
     "sosrt_plan_fix_count": (c_int, [c_double, c_int]),
+    "sosrt_debug_stamps": (c_int, [c_void_p, c_void_p]),
     "sosrt_microbench": (c_int, [c_void_p, c_int, _dp]),
     "sosrt_profile_enable": (c_int, [c_void_p, c_int]),
     "sosrt_profile_reset": (c_int, [c_void_p]),
