@@ -66,7 +66,8 @@ struct sosrt_handle {
     ColDesc* d_desc = nullptr;
     double *d_rca = nullptr, *d_rcr = nullptr;
     int* d_slabrows = nullptr;
-    int nslab = 0;
+    int* d_mainrows = nullptr;
+    int nslab = 0, nmain = 0;
     // device: fields (internal)
     double *d_tau = nullptr, *d_P0a = nullptr, *d_P0r = nullptr;
     double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr, *d_E = nullptr;
@@ -141,11 +142,16 @@ ColScalars scalars_of(sosrt_handle* h) {
     return sc;
 }
 
-// Jn for every row of the batch: main pass with W_atm, second pass over the slab rows with W_aer
+// Jn for every row of the batch in one launch: plain rows against W_atm, slab rows against W_atm and W_aer
 void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active) {
+    GemmArgs ga;
+    ga.A = In_1; ga.Wa = h->d_Wa; ga.Wr = h->d_Wr; ga.ca = h->d_rca; ga.cr = h->d_rcr;
+    ga.rows_main = h->nslab > 0 ? h->d_mainrows : nullptr;
+    ga.n_main = h->nslab > 0 ? h->nmain : h->B * h->L;
+    ga.rows_slab = h->d_slabrows; ga.n_slab = h->nslab;
+    ga.D = h->g.D; ga.Dp = h->g.Dp; ga.Wld = h->g.Wld; ga.L = h->L; ga.C = Jn; ga.active = active;
     prof_begin(h, SOSRT_K_GEMM);
-    launch_gemm(h->stream, h->g, In_1, h->d_Wa, h->d_rca, nullptr, h->B * h->L, Jn, 0, active);
-    if (h->nslab > 0) launch_gemm(h->stream, h->g, In_1, h->d_Wr, h->d_rcr, h->d_slabrows, h->nslab, Jn, 1, active);
+    launch_gemm(h->stream, ga);
     prof_end(h, SOSRT_K_GEMM);
 }
 
@@ -196,6 +202,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_rca, mb * L))) return e;
             if ((e = dalloc(&h->d_rcr, mb * L))) return e;
             if ((e = dalloc(&h->d_slabrows, mb * L))) return e;
+            if ((e = dalloc(&h->d_mainrows, mb * L))) return e;
             if ((e = dalloc(&h->d_tau, mb * L))) return e;
             if ((e = dalloc(&h->d_P0a, mb * g.D))) return e;
             if ((e = dalloc(&h->d_P0r, mb * g.D))) return e;
@@ -234,7 +241,7 @@ int sosrt_destroy(sosrt_t* h) {
         hipSetDevice(h->device);
         if (h->own_stream) hipStreamSynchronize(h->own_stream);
         void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
-                        h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_tau, h->d_P0a,
+                        h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio, h->d_redo};
         for (void* p : ptrs)
@@ -323,7 +330,7 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
     if (!mu0 || !alb_atm || !tauStar_tot) return fail(SOSRT_E_INVALID, "mu0, alb_atm and tauStar_tot are required");
     const size_t mb = h->max_batch;
     std::vector<double> sc(7 * mb, 0.0);
-    std::vector<int> slab;
+    std::vector<int> slab, plain;
     if (geometry == SOSRT_GEOM_THREE_ZONE) {
         if (!idx_up || !idx_down || !grd_alb || !alb_aer || !dtau_atm || !dtau_aer)
             return fail(SOSRT_E_INVALID, "three-zone geometry needs idx_up, idx_down, grd_alb, alb_aer, dtau_atm, dtau_aer");
@@ -333,7 +340,7 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
             if (idx_up[b] < 1 || idx_down[b] < idx_up[b] || idx_down[b] > h->L - 2)
                 return fail(SOSRT_E_INVALID, "column %d: need 1 <= idx_up <= idx_down <= nb_layers-2 (got %d, %d)", b,
                             idx_up[b], idx_down[b]);
-            for (int t = idx_up[b]; t <= idx_down[b]; ++t) slab.push_back(b * h->L + t);
+            for (int t = 0; t < h->L; ++t) (t >= idx_up[b] && t <= idx_down[b] ? slab : plain).push_back(b * h->L + t);
         }
     } else if (geometry == SOSRT_GEOM_SINGLE_SLAB) {
         surface = SOSRT_SURFACE_NONE;
@@ -357,9 +364,12 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
         HIPCHK(hipMemcpyAsync(h->d_idx_down, idx_down, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (!slab.empty())
             HIPCHK(hipMemcpyAsync(h->d_slabrows, slab.data(), slab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (!plain.empty())
+            HIPCHK(hipMemcpyAsync(h->d_mainrows, plain.data(), plain.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
     h->nslab = (int)slab.size();
+    h->nmain = (int)plain.size();
     h->B = B; h->geom = geometry; h->surface = surface;
     h->have_cols = true;
     return 0;
@@ -702,7 +712,7 @@ int sosrt_debug_stamps(sosrt_t* h, unsigned long long* d_stamps) {
 // ---------------------------------------------------------------------------------------------
 int sosrt_microbench(sosrt_t* h, int which, double* result) {
     if (int e = need_gpu(h)) return e;
-    if (!result || which < 0 || which > 2) return fail(SOSRT_E_INVALID, "bad argument");
+    if (!result || which < 0 || (which > 2 && which < 10) || which > 49) return fail(SOSRT_E_INVALID, "bad argument");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     hipEvent_t e0, e1;
@@ -725,7 +735,10 @@ int sosrt_microbench(sosrt_t* h, int which, double* result) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, e0, e1));
             double v;
-            if (which == 0) v = 2048.0 * 4 * (double)iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;        // TFLOP/s
+            if (which >= 10) {
+                const int code = which - 10, nacc = 2 << (code / 10), bpc = (code % 10) ? (code % 10) : 1;
+                v = 256.0 * bpc * 4 * (double)iters * nacc * 2048.0 / (ms * 1e-3) / 1e12;
+            } else if (which == 0) v = 2048.0 * 4 * (double)iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;        // TFLOP/s
             else if (which == 1) v = 2.0 * na * sizeof(double) / (ms * 1e-3) / 1e9;                  // GB/s read+write
             else v = 2048.0 * 256 * (double)iters * 16 * 2.0 / (ms * 1e-3) / 1e12;                   // TFLOP/s
             if (rep > 0 && v > best) best = v;

@@ -16,6 +16,7 @@
 
 namespace sosrt {
 
+
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define SOSRT_PI 3.14159265358979323846
@@ -273,122 +274,6 @@ void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, 
     const size_t shm = (size_t)(g.L + nt + nt / 64 + 2) * sizeof(double);
     hipLaunchKernelGGL(k_first_order, dim3(B), dim3(nt), shm, s, g, tau, P0a, P0r, desc, I1_out, I_out, saved,
                        saved_col_stride, cv, do_conv);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_jn_gemm:  C[r][:] (+)= coef[r] * (A[r][:] @ W)      rows r = layers of all columns
-//
-// FP64 MFMA (v_mfma_f64_16x16x4_f64): lane l supplies A[i = l&15][k = l>>4] and
-// B[k = l>>4][j = l&15]; the 4 results of lane l are D[i = 4r + (l>>4)][j = l&15], r = 0..3.
-// Workgroup tile 64 rows x 128 columns, 4 waves, each wave 4x2 MFMA tiles; operands staged
-// through LDS in k-chunks of 16 with row strides chosen so that ds_read_b64 is conflict-free
-// (A: stride 18 doubles = 36 dwords, 36/4 odd; B: stride 144 doubles = 288 = 32 mod 64 dwords).
-// ------------------------------------------------------------------------------------------
-constexpr int A_LD = GEMM_KC + 2;
-constexpr int B_LD = GEMM_BN + 16;
-
-__global__ __launch_bounds__(256) void k_jn_gemm(const double* __restrict__ A, const double* __restrict__ W,
-                                                 const double* __restrict__ coef, const int* __restrict__ rowlist,
-                                                 int nrows, int D, int Dp, int Wld, int L,
-                                                 double* __restrict__ C, int accumulate,
-                                                 const int* __restrict__ active) {
-    __shared__ double sA[GEMM_BM * A_LD];
-    __shared__ double sB[GEMM_KC * B_LD];
-    __shared__ int s_any;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bm0 = blockIdx.x * GEMM_BM, bn0 = blockIdx.y * GEMM_BN;
-
-    // rows of this tile; skip the tile when every column it touches has converged
-    const int arow = tid >> 2, akq = (tid & 3) * 4;
-    int grow = -1;
-    if (bm0 + arow < nrows) grow = rowlist ? rowlist[bm0 + arow] : bm0 + arow;
-    if (active) {
-        if (tid == 0) s_any = 0;
-        __syncthreads();
-        if ((tid & 3) == 0 && grow >= 0 && active[grow / L]) s_any = 1;
-        __syncthreads();
-        if (!s_any) return;
-    }
-
-    f64x4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
-
-    const int bk = tid >> 4, bc = (tid & 15) * 8;
-    const double* Arow = grow >= 0 ? A + (size_t)grow * D : A;
-    const int fr = lane & 15, fk = lane >> 4;
-
-    // software pipeline: the global loads of chunk k+1 are in flight while chunk k is multiplied
-    double2 a01, a23, b0, b1, b2, b3;
-    auto gload = [&](int kc) {
-        a01 = make_double2(0, 0); a23 = make_double2(0, 0);
-        const int k0 = kc + akq;
-        if (grow >= 0) {
-            if (k0 + 1 < D) a01 = *reinterpret_cast<const double2*>(Arow + k0);
-            if (k0 + 3 < D) a23 = *reinterpret_cast<const double2*>(Arow + k0 + 2);
-        }
-        const double* Wp = W + (size_t)(kc + bk) * Wld + bn0 + bc;
-        b0 = *reinterpret_cast<const double2*>(Wp);
-        b1 = *reinterpret_cast<const double2*>(Wp + 2);
-        b2 = *reinterpret_cast<const double2*>(Wp + 4);
-        b3 = *reinterpret_cast<const double2*>(Wp + 6);
-    };
-    gload(0);
-    for (int kc = 0; kc < Dp; kc += GEMM_KC) {
-        __syncthreads();   // previous chunk consumed
-        *reinterpret_cast<double2*>(&sA[arow * A_LD + akq]) = a01;
-        *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2]) = a23;
-        double* sb = &sB[bk * B_LD + bc];
-        *reinterpret_cast<double2*>(sb) = b0;
-        *reinterpret_cast<double2*>(sb + 2) = b1;
-        *reinterpret_cast<double2*>(sb + 4) = b2;
-        *reinterpret_cast<double2*>(sb + 6) = b3;
-        __syncthreads();
-        if (kc + GEMM_KC < Dp) gload(kc + GEMM_KC);
-#pragma unroll
-        for (int kk = 0; kk < GEMM_KC; kk += 4) {
-            double af[4], bf[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = sA[(i * 16 + fr) * A_LD + kk + fk];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = sB[(kk + fk) * B_LD + wave * 32 + j * 16 + fr];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    // epilogue: lane holds column (l & 15), rows 4r + (l >> 4)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int lr = bm0 + i * 16 + 4 * r + fk;
-            if (lr >= nrows) continue;
-            const int gr = rowlist ? rowlist[lr] : lr;
-            const double cf = coef[gr];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = bn0 + wave * 32 + j * 16 + fr;
-                if (col < D) {
-                    double* p = C + (size_t)gr * D + col;
-                    const double v = cf * acc[i][j][r];
-                    *p = accumulate ? (*p + v) : v;
-                }
-            }
-        }
-    }
-}
-
-void launch_gemm(hipStream_t s, const Grid& g, const double* A, const double* W, const double* coef,
-                 const int* rowlist, int nrows, double* C, int accumulate, const int* active) {
-    if (nrows <= 0) return;
-    dim3 grid((nrows + GEMM_BM - 1) / GEMM_BM, (g.D + GEMM_BN - 1) / GEMM_BN);
-    hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), 0, s, A, W, coef, rowlist, nrows, g.D, g.Dp, g.Wld, g.L, C,
-                       accumulate, active);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -979,18 +864,19 @@ void launch_asymptotic(hipStream_t s, int R, int stride, const int* len, const d
 // ------------------------------------------------------------------------------------------
 // machine peaks measured on the box (denominators of the roofline fractions)
 // ------------------------------------------------------------------------------------------
+template <int NACC>
 __global__ __launch_bounds__(256) void k_bench_mfma_f64(double* out, int iters) {
-    f64x4 acc[8];
+    f64x4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (f64x4){0, 0, 0, 0};
+    for (int i = 0; i < NACC; ++i) acc[i] = (f64x4){0, 0, 0, 0};
     const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double sres = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sres += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < NACC; ++i) sres += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (sres == 12345.678) out[0] = sres;          // keeps the loop alive
 }
 
@@ -1015,7 +901,17 @@ __global__ __launch_bounds__(256) void k_bench_copy(const double2* __restrict__ 
 }
 
 void launch_bench(hipStream_t s, int which, double* a, double* b, size_t n, int iters) {
-    if (which == 0) hipLaunchKernelGGL(k_bench_mfma_f64, dim3(2048), dim3(256), 0, s, a, iters);
+    // which >= 10: MFMA variants, (which-10) = nacc_code*10 + blocks_per_cu_code; flops are per launch_bench_flops
+    if (which >= 10) {
+        const int code = which - 10, nacc = code / 10, bpc = code % 10;     // bpc: workgroups (4 waves) per CU
+        const dim3 grid(256 * (bpc ? bpc : 1)), block(256);
+        if (nacc == 0) hipLaunchKernelGGL(k_bench_mfma_f64<2>, grid, block, 0, s, a, iters);
+        else if (nacc == 1) hipLaunchKernelGGL(k_bench_mfma_f64<4>, grid, block, 0, s, a, iters);
+        else if (nacc == 2) hipLaunchKernelGGL(k_bench_mfma_f64<8>, grid, block, 0, s, a, iters);
+        else hipLaunchKernelGGL(k_bench_mfma_f64<16>, grid, block, 0, s, a, iters);
+        return;
+    }
+    if (which == 0) hipLaunchKernelGGL(k_bench_mfma_f64<8>, dim3(2048), dim3(256), 0, s, a, iters);
     else if (which == 1) hipLaunchKernelGGL(k_bench_copy, dim3(2048), dim3(256), 0, s, (const double2*)a, (double2*)b, n / 2);
     else hipLaunchKernelGGL(k_bench_fma_f64, dim3(2048), dim3(256), 0, s, a, iters);
 }

@@ -67,7 +67,7 @@ struct Conv {
     double tol;
 };
 
-constexpr int GEMM_BM = 64, GEMM_BN = 128, GEMM_KC = 16;
+constexpr int GEMM_BM = 64, GEMM_BN = 128, GEMM_KC = 32;
 
 // Transport rows are processed in chunks of TC: the loads of the next chunks are in flight while
 // the current one is computed, the per-row source terms of a chunk are independent
@@ -98,8 +98,24 @@ void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, 
 void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, const double* P0a, const double* P0r,
                         const ColDesc* desc, double* I1_out, double* I_out, double* saved, size_t saved_col_stride,
                         Conv cv, int do_conv);
-void launch_gemm(hipStream_t s, const Grid& g, const double* A, const double* W, const double* coef,
-                 const int* rowlist, int nrows, double* C, int accumulate, const int* active);
+// Jn = diag(ca) A Wa for the rows of `rows_main`, and diag(ca) A Wa + diag(cr) A Wr for the rows of
+// `rows_slab` (spec:321), in one launch.  Row lists hold global row ids; rows_main == nullptr means
+// the identity list 0..n_main-1.
+struct GemmArgs {
+    const double* A;
+    const double* Wa;
+    const double* Wr;
+    const double* ca;      // per-row coefficients
+    const double* cr;
+    const int* rows_main;
+    int n_main;
+    const int* rows_slab;
+    int n_slab;
+    int D, Dp, Wld, L;
+    double* C;
+    const int* active;     // nullable: skip tiles whose columns have all converged
+};
+void launch_gemm(hipStream_t s, const GemmArgs& a);
 void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
