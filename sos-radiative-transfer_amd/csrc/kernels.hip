@@ -170,6 +170,15 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
     const double c4pi = 1.0 / (4 * SOSRT_PI);
     const bool valid = tid < N;
     double rdn = 0, rup = 0;                                // ratios of the first loop test (In = ones)
+    // the two beam attenuations of a layer do not depend on the direction: once per row, in LDS
+    double* s_e0 = s_red + (blockDim.x >> 6) + 2;           // [L] exp(-tau/mu0)
+    double* s_eT = s_e0 + L;                                // [L] exp(-(T - tau)/mu0)
+    for (int t = tid; t < L; t += blockDim.x) {
+        s_e0[t] = exp(-s_tau[t] / mu0);
+        s_eT[t] = exp(-(T - s_tau[t]) / mu0);
+    }
+    __syncthreads();
+    constexpr int FU = 4;    // rows of a zone are independent: FU of them are evaluated together
 
     // ---- downward, m = tid ----
     {
@@ -180,35 +189,45 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         const double qx = (d.wa * P0a[mm] * d.fa + d.wr * P0r[mm] * d.fr) * c4pi;
         const double qxm = (d.wa * P0a[mir] * d.fa + d.wr * P0r[mir] * d.fr) * c4pi;
         const bool near = fabs(mu + mu0) < 0.0001;          // spec:111
-        double Ib = 0, v = 0;
+        const bool node = m > N - 2;                         // the mu = 0- node (spec:128-131)
+        const double gd = mu0 / (mu0 + mu), gs = mu0 / (mu0 - mu);
+        double Ib = 0, vlast = 0;
         for (int z = 0; z < d.nz; ++z) {
             const double q = d.mix[z] ? qx : qa, qm = d.mix[z] ? qxm : qam;
             const double t_bd = z ? s_tau[d.r0[z] - 1] : 0.0;
             const double t_bs = z ? s_tau[d.r0[z]] : 0.0;
             const double e_bd = exp(-t_bd / mu0), e_bs = exp(-(T - t_bs) / mu0);
-            for (int t = d.r0[z]; t <= d.r1[z]; ++t) {
-                const double tt = s_tau[t];
-                const double e0 = exp(-tt / mu0), eT = exp(-(T - tt) / mu0);
-                if (m <= N - 2) {
-                    const double x = exp((tt - t_bd) / mu);
+            const int r0 = d.r0[z], r1 = d.r1[z];
+            for (int tb = r0; tb <= r1; tb += FU) {
+                double v[FU];
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int t = min(tb + u, r1);
+                    const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
+                    const double x = exp((tt - t_bd) / mu), xs = exp((tt - t_bs) / mu);
                     const double before = z ? Ib * x : 0.0;
-                    const double direct = near ? q * F0 * e0 * (tt - t_bd) / mu0
-                                               : (mu0 / (mu0 + mu)) * q * F0 * (e0 - e_bd * x);
-                    const double surf = (mu0 / (mu0 - mu)) * qm * R * (eT - e_bs * exp((tt - t_bs) / mu));
-                    v = before + direct + surf;
-                } else {                                     // the mu = 0- node (spec:128-131)
-                    v = (mu0 / (mu0 + mu)) * q * F0 * e0 + (mu0 / (mu0 - mu)) * qm * R * eT;
+                    const double direct = near ? q * F0 * e0 * (tt - t_bd) / mu0 : gd * q * F0 * (e0 - e_bd * x);
+                    const double surf = gs * qm * R * (eT - e_bs * xs);
+                    const double vnode = gd * q * F0 * e0 + gs * qm * R * eT;
+                    v[u] = node ? vnode : before + direct + surf;
                 }
-                if (valid) {
-                    I1[(size_t)t * D + m] = v;
-                    if (Iacc) Iacc[(size_t)t * D + m] = v;
-                    if (sv) sv[(size_t)t * D + m] = v;
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int t = tb + u;
+                    if (t <= r1) {
+                        if (valid) {
+                            I1[(size_t)t * D + m] = v[u];
+                            if (Iacc) Iacc[(size_t)t * D + m] = v[u];
+                            if (sv) sv[(size_t)t * D + m] = v[u];
+                        }
+                        vlast = v[u];
+                    }
                 }
             }
-            Ib = v;
+            Ib = vlast;
         }
-        s_sfc[tid] = v;                                       // I1[L-1][m]
-        rdn = 1.0 / v;
+        s_sfc[tid] = vlast;                                   // I1[L-1][m]
+        rdn = 1.0 / vlast;
     }
     __syncthreads();
     // ---- upward, m = N + tid, zones bottom to top ----
@@ -219,8 +238,10 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         const double qx = (d.wa * P0a[m] * d.fa + d.wr * P0r[m] * d.fr) * c4pi;
         const double qxm = (d.wa * P0a[mir] * d.fa + d.wr * P0r[mir] * d.fr) * c4pi;
         const bool near = fabs(mu - mu0) < 0.0001;           // spec:204
+        const bool node = j < 1;                             // the mu = 0+ node (spec:221-224)
+        const double gd = mu0 / (mu0 + mu), gs = mu0 / (mu0 - mu);
         double Bv = rho * s_sfc[mir];                          // spec:211
-        double v = 0;
+        double vlast = 0;
         for (int z = d.nz - 1; z >= 0; --z) {
             const bool bottom = z == d.nz - 1;
             const double q = d.mix[z] ? qx : qa, qm = d.mix[z] ? qxm : qam;
@@ -228,27 +249,36 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             const double t_bb = bottom ? s_tau[L - 1] : t_bu;
             const double t_su = bottom ? T : s_tau[d.r1[z]];
             const double e_bu = exp(-t_bu / mu0), e_su = exp(-(T - t_su) / mu0);
-            for (int t = d.r1[z]; t >= d.r0[z]; --t) {
-                const double tt = s_tau[t];
-                const double e0 = exp(-tt / mu0), eT = exp(-(T - tt) / mu0);
-                if (j >= 1) {
-                    const double before = Bv * exp(-(t_bb - tt) / mu);
-                    const double direct = (mu0 / (mu0 + mu)) * q * F0 * (e0 - e_bu * exp(-(t_bu - tt) / mu));
-                    const double surf = near ? qm * R * eT * (t_su - tt) / mu0
-                                             : (mu0 / (mu0 - mu)) * qm * R * (eT - e_su * exp(-(t_su - tt) / mu));
-                    v = before + direct + surf;
-                } else {                                     // the mu = 0+ node (spec:221-224)
-                    v = (mu0 / (mu0 + mu)) * q * F0 * e0 + (mu0 / (mu0 - mu)) * qm * R * eT;
+            const int r0 = d.r0[z], r1 = d.r1[z];
+            for (int tb = r1; tb >= r0; tb -= FU) {
+                double v[FU];
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int t = max(tb - u, r0);
+                    const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
+                    const double yb = exp(-(t_bb - tt) / mu), yu = exp(-(t_bu - tt) / mu), ys = exp(-(t_su - tt) / mu);
+                    const double before = Bv * yb;
+                    const double direct = gd * q * F0 * (e0 - e_bu * yu);
+                    const double surf = near ? qm * R * eT * (t_su - tt) / mu0 : gs * qm * R * (eT - e_su * ys);
+                    const double vnode = gd * q * F0 * e0 + gs * qm * R * eT;
+                    v[u] = node ? vnode : before + direct + surf;
                 }
-                if (valid) {
-                    I1[(size_t)t * D + m] = v;
-                    if (Iacc) Iacc[(size_t)t * D + m] = v;
-                    if (sv) sv[(size_t)t * D + m] = v;
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int t = tb - u;
+                    if (t >= r0) {
+                        if (valid) {
+                            I1[(size_t)t * D + m] = v[u];
+                            if (Iacc) Iacc[(size_t)t * D + m] = v[u];
+                            if (sv) sv[(size_t)t * D + m] = v[u];
+                        }
+                        vlast = v[u];
+                    }
                 }
             }
-            Bv = v;                                           // row r0 of this zone feeds the zone above
+            Bv = vlast;                                       // row r0 of this zone feeds the zone above
         }
-        rup = 1.0 / v;                                        // v = I1[0][m]
+        rup = 1.0 / vlast;                                    // I1[0][m]
     }
     if (do_conv) {
         const double a = block_pymax(rup, valid, s_red);
@@ -271,7 +301,7 @@ void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, 
                         const ColDesc* desc, double* I1_out, double* I_out, double* saved, size_t saved_col_stride,
                         Conv cv, int do_conv) {
     const int nt = round64(g.N);
-    const size_t shm = (size_t)(g.L + nt + nt / 64 + 2) * sizeof(double);
+    const size_t shm = (size_t)(3 * g.L + nt + nt / 64 + 4) * sizeof(double);
     hipLaunchKernelGGL(k_first_order, dim3(B), dim3(nt), shm, s, g, tau, P0a, P0r, desc, I1_out, I_out, saved,
                        saved_col_stride, cv, do_conv);
 }
