@@ -27,37 +27,37 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int A_LD = GEMM_KC + 2;
 constexpr int B_LD = GEMM_BN + 16;
 
-__global__ __launch_bounds__(256, 2) void k_jn_gemm(GemmArgs g) {
-    __shared__ double sA[GEMM_BM * A_LD];
-    __shared__ double sB[GEMM_KC * B_LD];
-    __shared__ int s_any;
+// RT = MFMA row tiles per wave: 4 (64 rows) for the plain rows, 2 (32 rows) for the slab rows, whose
+// two passes over k would otherwise make their workgroups the critical path of the launch.
+template <int RT, bool SLAB>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile) {
+    constexpr int BM = 16 * RT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int D = g.D, Dp = g.Dp, Wld = g.Wld;
-    const int tiles_main = (g.n_main + GEMM_BM - 1) / GEMM_BM;
-    const bool slab = (int)blockIdx.x >= tiles_main;                 // uniform
+    constexpr bool slab = SLAB;
     const int* __restrict__ rows = slab ? g.rows_slab : g.rows_main;
     const int nrows = slab ? g.n_slab : g.n_main;
-    const int bm0 = (slab ? (int)blockIdx.x - tiles_main : (int)blockIdx.x) * GEMM_BM, bn0 = blockIdx.y * GEMM_BN;
+    const int bm0 = tile * BM, bn0 = blockIdx.y * GEMM_BN;
 
     // the row this thread stages, its coefficients; skip the tile when every column it touches has converged
     const int arow = tid >> 2, akq = (tid & 3) * 8;
     int grow = -1;
-    if (bm0 + arow < nrows) grow = rows ? rows[bm0 + arow] : bm0 + arow;
+    if (arow < BM && bm0 + arow < nrows) grow = rows ? rows[bm0 + arow] : bm0 + arow;
     if (g.active) {
-        if (tid == 0) s_any = 0;
+        if (tid == 0) *s_any = 0;
         __syncthreads();
-        if ((tid & 3) == 0 && grow >= 0 && g.active[grow / g.L]) s_any = 1;
+        if ((tid & 3) == 0 && grow >= 0 && g.active[grow / g.L]) *s_any = 1;
         __syncthreads();
-        if (!s_any) return;
+        if (!*s_any) return;
     }
     const double coef_a = grow >= 0 ? g.ca[grow] : 0.0;
     const double coef_r = (slab && grow >= 0) ? g.cr[grow] : 0.0;
     const double* __restrict__ Arow = g.A + (size_t)(grow >= 0 ? grow : 0) * D;
 
-    f64x4 acc[4][2];
+    f64x4 acc[RT][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
 
@@ -66,23 +66,33 @@ __global__ __launch_bounds__(256, 2) void k_jn_gemm(GemmArgs g) {
     const int nck = Dp / GEMM_KC;                 // chunks per pass
     const int ntot = slab ? 2 * nck : nck;
 
-    // Register staging buffers as plain named values (arrays passed through lambdas end up in scratch).
-    struct Stage { double2 a[4]; double2 b[8]; };
-    Stage s0, s1;
+    // Register staging as plain named values (arrays passed through lambdas end up in scratch).  The A
+    // operand (In_1, from HBM) is staged two chunks ahead, the W operand (L2-resident) one chunk ahead.
+    struct StageA { double2 a[4]; };
+    StageA s0, s1;
+    double2 sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;     // named: an array here ends up in scratch
     // global -> registers for chunk c (clamped: every call issues the same loads)
-#define SOSRT_GLOAD(ST, c_)                                                                               \
+#define SOSRT_GLOAD_A(ST, c_)                                                                             \
     {                                                                                                     \
         const int cc_ = min((c_), ntot - 1);                                                              \
-        const int pass_ = cc_ >= nck ? 1 : 0;                                                             \
-        const int kc_ = (cc_ - pass_ * nck) * GEMM_KC;                                                    \
-        const double* __restrict__ W_ = pass_ ? g.Wr : g.Wa;                                              \
+        const int kc_ = (cc_ >= nck ? cc_ - nck : cc_) * GEMM_KC;                                         \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
             const int k0_ = kc_ + akq + 2 * q;                                                            \
             ST.a[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + k0_)          \
                                                  : make_double2(0, 0);                                    \
         }                                                                                                 \
+    }
+#define SOSRT_GLOAD_B(c_)                                                                                 \
+    {                                                                                                     \
+        const int cc_ = min((c_), ntot - 1);                                                              \
+        const int pass_ = cc_ >= nck ? 1 : 0;                                                             \
+        const int kc_ = (cc_ - pass_ * nck) * GEMM_KC;                                                    \
+        const double* __restrict__ W_ = pass_ ? g.Wr : g.Wa;                                              \
         const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bn0 + bc;                                     \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) ST.b[q] = *reinterpret_cast<const double2*>(Wp_ + 2 * q); \
+        sb0 = *reinterpret_cast<const double2*>(Wp_); sb1 = *reinterpret_cast<const double2*>(Wp_ + 2);    \
+        sb2 = *reinterpret_cast<const double2*>(Wp_ + 4); sb3 = *reinterpret_cast<const double2*>(Wp_ + 6); \
+        sb4 = *reinterpret_cast<const double2*>(Wp_ + 8); sb5 = *reinterpret_cast<const double2*>(Wp_ + 10); \
+        sb6 = *reinterpret_cast<const double2*>(Wp_ + 12); sb7 = *reinterpret_cast<const double2*>(Wp_ + 14); \
     }
 #define SOSRT_LSTORE(ST, c_)                                                                              \
     {                                                                                                     \
@@ -90,45 +100,50 @@ __global__ __launch_bounds__(256, 2) void k_jn_gemm(GemmArgs g) {
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                     \
             *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                                 \
                 make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                           \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                     \
-            *reinterpret_cast<double2*>(&sB[bk * B_LD + bc + 2 * q]) = ST.b[q];                           \
+        double2* sbp_ = reinterpret_cast<double2*>(&sB[bk * B_LD + bc]);                                  \
+        sbp_[0] = sb0; sbp_[1] = sb1; sbp_[2] = sb2; sbp_[3] = sb3;                                       \
+        sbp_[4] = sb4; sbp_[5] = sb5; sbp_[6] = sb6; sbp_[7] = sb7;                                       \
     }
     auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < GEMM_KC; kk += 4) {
-            double af[4], bf[2];
+            double af[RT], bf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = sA[(i * 16 + fr) * A_LD + kk + fk];
+            for (int i = 0; i < RT; ++i) af[i] = sA[(i * 16 + fr) * A_LD + kk + fk];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = sB[(kk + fk) * B_LD + wave * 32 + j * 16 + fr];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
 
-    SOSRT_GLOAD(s0, 0);
-    SOSRT_GLOAD(s1, 1);
+    SOSRT_GLOAD_A(s0, 0);
+    SOSRT_GLOAD_A(s1, 1);
+    SOSRT_GLOAD_B(0);
     for (int c = 0; c < ntot; c += 2) {
         __syncthreads();                 // previous chunk consumed
         SOSRT_LSTORE(s0, c);
         __syncthreads();
-        SOSRT_GLOAD(s0, c + 2);
+        SOSRT_GLOAD_A(s0, c + 2);
+        SOSRT_GLOAD_B(c + 1);
         compute();
         if (c + 1 >= ntot) break;
         __syncthreads();
         SOSRT_LSTORE(s1, c + 1);
         __syncthreads();
-        SOSRT_GLOAD(s1, c + 3);
+        SOSRT_GLOAD_A(s1, c + 3);
+        SOSRT_GLOAD_B(c + 2);
         compute();
     }
-#undef SOSRT_GLOAD
+#undef SOSRT_GLOAD_A
+#undef SOSRT_GLOAD_B
 #undef SOSRT_LSTORE
     // epilogue: lane holds column (l & 15), rows 4r + (l >> 4)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int lr = bm0 + i * 16 + 4 * r + fk;
@@ -144,10 +159,19 @@ __global__ __launch_bounds__(256, 2) void k_jn_gemm(GemmArgs g) {
     }
 }
 
+__global__ __launch_bounds__(256, 2) void k_jn_gemm(GemmArgs g) {
+    __shared__ double sA[GEMM_BM * A_LD];
+    __shared__ double sB[GEMM_KC * B_LD];
+    __shared__ int s_any;
+    const int tiles_main = (g.n_main + GEMM_BM - 1) / GEMM_BM;
+    if ((int)blockIdx.x < tiles_main) gemm_tile<4, false>(g, sA, sB, &s_any, blockIdx.x);
+    else gemm_tile<2, true>(g, sA, sB, &s_any, (int)blockIdx.x - tiles_main);
+}
+
 }  // namespace
 
 void launch_gemm(hipStream_t s, const GemmArgs& a) {
-    const int tiles = (a.n_main + GEMM_BM - 1) / GEMM_BM + (a.n_slab + GEMM_BM - 1) / GEMM_BM;
+    const int tiles = (a.n_main + GEMM_BM - 1) / GEMM_BM + (a.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);
     if (tiles <= 0) return;
     dim3 grid(tiles, (a.D + GEMM_BN - 1) / GEMM_BN);
     hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), 0, s, a);
