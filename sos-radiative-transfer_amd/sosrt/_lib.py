@@ -53,6 +53,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64 under torch/lib with the same
+    soname as the system ones.  Whichever copy is loaded first serves the whole process, and mixing the
+    system HIP runtime with torch's HSA runtime leaves torch without a GPU.  When torch is installed,
+    load its copy first (without importing torch), so that the order of `import torch` and the first
+    sosrt call does not matter."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """The loaded library; raises ImportError when it has not been built."""
     global _lib
@@ -61,6 +82,7 @@ def lib():
             raise ImportError(
                 "libsosrt.so not found at %s: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

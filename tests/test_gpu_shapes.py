@@ -1,0 +1,93 @@
+"""More shapes through the HIP path: the BASELINE configs C3 (N=256) and C5 (L=400, N=256), direction
+counts that are not a multiple of the wavefront, thin slabs, the order budget.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import sos_oracle as O
+from sosrt import _lib, inputs
+from sosrt.main import SOS_Aer_batch
+from sosrt.solver import Solver
+from util import RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(mu0, taer, rho, L, N, P_atm, P_aer, z_up, z_down, alb_aer, surface="specular"):
+    mu = inputs.direction_grid(N)
+    P0a = inputs.phase_function("rayleigh", N, mu, mu0)[0]
+    P0r = inputs.phase_function("hg", N, mu, mu0, 0.7)[0]
+    col = O.make_column(mu0, 120, z_up, z_down, L, 0.124, taer, rho, 1.0, alb_aer, N, P0a, P_atm, P0r, P_aer, surface=surface)
+    return O.solve_column(col, literal=False)
+
+
+@pytest.mark.parametrize("L,N,zs,cols", [
+    (200, 256, (25, 17), [(0.5, 0.12, 0.15)]),                                   # C3: EVA-like column, D = 512
+    (400, 256, (15, 14), [(0.5, 0.0075, 0.15), (0.3, 0.05, 0.6)]),               # C5: wildfire slab (thin), L = 400
+    (64, 48, (30, 10), [(0.7, 0.3, 0.2), (0.25, 1.0, 0.0)]),                     # 48 directions: one partly filled wave
+    (50, 70, (40, 20), [(0.6, 0.2, 0.1), (0.9, 0.5, 0.2)]),                      # 70: extrapolation straddles two waves -> general kernel
+    (90, 192, (25, 17), [(0.4, 0.12, 0.3)]),                                     # three waves per sweep
+])
+def test_shapes_match_oracle(L, N, zs, cols):
+    mu = inputs.direction_grid(N)
+    P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
+    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    m0, ta, rh = (np.array(x) for x in zip(*cols))
+    r = SOS_Aer_batch(m0, ta, rh, tauStar_atm=0.124, alb_aer=0.97, nb_layers=L, nb_angles=N, z_up=zs[0], z_down=zs[1],
+                      P_atm=P_atm, P_aer=P_aer, max_orders=200, raise_on_error=False)
+    for b, (a, t, g) in enumerate(cols):
+        try:
+            ref = _oracle(a, t, g, L, N, P_atm, P_aer, zs[0], zs[1], 0.97)
+        except IndexError:
+            assert r.status[b] == _lib.COL_INDEXERROR
+            continue
+        assert r.status[b] == _lib.COL_OK and r.n[b] == ref.n, (b, r.status[b], r.n[b], ref.n)
+        assert_close(r.I[b], ref.I, RTOL, "L=%d N=%d column %d" % (L, N, b))
+
+
+def test_order_budget_is_reported():
+    L, N = 40, 32
+    mu = inputs.direction_grid(N)
+    P = inputs.phase_function("iso", N, mu, 0.5)[1]
+    r = SOS_Aer_batch([0.5, 0.5], [0.05, 1.0], [0.1, 0.7], nb_layers=L, nb_angles=N, z_up=60, z_down=20, P_atm=P, P_aer=P,
+                      atm_phase_fun="iso", aer_phase_fun="iso", max_orders=6, raise_on_error=False)
+    assert r.status[1] == _lib.COL_MAXORDERS and r.n[1] == 6
+    ok = SOS_Aer_batch([0.5], [0.05], [0.1], nb_layers=L, nb_angles=N, z_up=60, z_down=20, P_atm=P, P_aer=P,
+                       atm_phase_fun="iso", aer_phase_fun="iso", max_orders=64)
+    if r.status[0] == _lib.COL_OK:
+        assert r.n[0] == ok.n[0] and np.array_equal(r.I[0], ok.I[0])
+
+
+def test_saved_orders_on_device_path_and_stats():
+    """solve_dev with an I_saved buffer (device pointers through torch)."""
+    import torch
+    L, N, B = 50, 32, 3
+    mu = inputs.direction_grid(N)
+    P0, P = inputs.phase_function("iso", N, mu, 0.5)
+    iu, idn = inputs.slab_indices(120, 25, 17, L)
+    taer = np.array([0.05, 0.12, 0.4])
+    tau = np.stack([inputs.tau_profile(0.104, t, 120, 25, 17, L) for t in taer])
+    s = Solver(L, N, max_batch=B, max_orders=40)
+    dev = torch.device("cuda", 0)
+    s.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    s.set_grid(mu)
+    s.set_phase(P, P)
+    s.set_columns(np.full(B, iu), np.full(B, idn), 0.5, 0.15, 1.0, 1.0, 0.104 / L, taer / (idn + 1 - iu), 0.104 + taer)
+    d_tau = torch.from_numpy(tau).to(dev)
+    d_P0 = torch.from_numpy(np.tile(P0, (B, 1))).to(dev)
+    d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev)
+    d_sv = torch.zeros((B, 40, L, 2 * N), dtype=torch.float64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    s.solve_device(d_tau.data_ptr(), d_P0.data_ptr(), d_P0.data_ptr(), d_I.data_ptr(), d_I_saved=d_sv.data_ptr(),
+                   d_n_orders=d_n.data_ptr())
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    mo, so = s.last_solve_stats()
+    assert so == int((n - 1).sum()) and mo >= n.max()
+    I, sv = d_I.cpu().numpy(), d_sv.cpu().numpy()
+    for b in range(B):
+        assert_close(sv[b, :n[b]].sum(axis=0), I[b], 1e-13, "sum of saved orders")
+        assert not sv[b, n[b]:].any()
+    g = np.load(__import__("util").golden("g3_spec_C1_iso.npz")[0])
+    assert n[1] == int(g["n"])
+    assert_close(I[1], g["I"], RTOL, "C1 column through the device path")
+    s.close()
