@@ -93,10 +93,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    # the driver launches one rank per GPU over RCCL; SOSRT_BENCH_BACKEND=gloo + SOSRT_BENCH_SHARE_GPU=1 lets the
+    # tests rehearse the multi-rank path with two ranks on a one-GPU box
+    backend = os.environ.get("SOSRT_BENCH_BACKEND", "nccl")
+    if os.environ.get("SOSRT_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     ge.build()
@@ -159,6 +167,9 @@ def main():
             dig, ev = f.result()
             if world > 1:
                 main_stream.wait_event(ev)
+                if backend != "nccl":                 # gloo gathers host tensors
+                    ev.synchronize()
+                    dig = dig.cpu()
                 bufs = [torch.empty_like(dig) for _ in range(world)] if rank == 0 else None
                 dist.gather(dig, bufs, dst=0)
 
@@ -188,7 +199,7 @@ def main():
         fo_ms += ln.s.profile_get(_lib.K_FIRST)[0]
         ln.s.profile_enable(False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -200,6 +211,7 @@ def main():
         # (column, order) pair (no credit for the second slab matrix or for padding).
         flops = 2.0 * L * D * D * orders_per_step * a.steps
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        tr_gbs = 40.0 * L * D * orders_per_step * a.steps / (tr_ms * 1e-3) / 1e9 if tr_ms > 0 else 0.0
         out = {
             "metric": "SOS columns/sec to 1e-4 convergence (Ntau=200, Nmu=128)",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -213,6 +225,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_jn_gemm", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": gemm_ms / max(gemm_launches, 1), "launches": gemm_launches},
+            # second kernel of the order loop, HBM-bound: reads Jn, E, I and writes In, I = 40 L D bytes per column.order
+            "roofline_transport": {"bound": "hbm", "kernel": "k_transport_fast", "achieved": tr_gbs, "peak": 8000.0,
+                                   "unit": "GB/s", "frac": tr_gbs / 8000.0, "traffic": None},
             "kernel_ms_per_step": {"k_jn_gemm": gemm_ms / a.steps, "k_transport": tr_ms / a.steps,
                                    "k_first_order": fo_ms / a.steps},
         }

@@ -1,0 +1,40 @@
+"""bench.py end to end: the single-GPU line, and the multi-rank path rehearsed with two gloo ranks that
+share the one GPU of the test box (the driver runs the real N = 2, 4, 8 over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--columns", "64", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["unit"] == "columns/s" and d["value"] > 0 and d["dtype"] == "f64"
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["config"]["not_converged"] == 0 and d["config"]["columns_per_gpu"] == 64
+
+
+def test_bench_two_ranks_share_the_gpu():
+    env = dict(os.environ, SOSRT_BENCH_BACKEND="gloo", SOSRT_BENCH_SHARE_GPU="1")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--columns", "27",
+           "--inflight", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["columns_per_gpu"] == 27 and "cpu_baseline" not in d
