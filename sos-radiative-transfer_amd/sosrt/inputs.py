@@ -2,11 +2,15 @@
 
 These are host-side (NumPy) builders for the arrays the reference's drivers
 construct before the order loop (SOS_Aer_tau_profile.py, SOS_Aer_phase_func.py);
-they are not on the timed path.  Mie-derived phase functions ('mie', 'eva',
-'wildfire') need the third-party `miepython`, which is not available offline:
-pass pre-built (P0, P) arrays for those.
+they are not on the timed path.  'iso', 'rayleigh' and 'hg' are pinned to the
+reference's outputs (tests/golden/g5_*).  The Mie-derived functions ('mie',
+'eva', 'wildfire') follow the reference's recipe on top of this package's own
+Mie series (sosrt/mie.py) because `miepython` is not available offline: their
+parity is unpinned.
 """
 import numpy as np
+
+from . import mie as _mie
 
 _trapz = getattr(np, "trapezoid", None) or np.trapz
 
@@ -50,14 +54,35 @@ def _azimuth_averaged(p, mu, mu0):
     return P0, 4 * S / _trapz(S, mu, axis=0)[None, :]
 
 
-def phase_function(name, nb_angles, mu, mu0, g=0.0):
-    """'iso' | 'rayleigh' | 'hg' (SOS_Aer_phase_func.py:68,79,141)."""
+_bulk_cache = {}
+
+
+def _bulk(name, **kw):
+    key = (name,) + tuple(sorted(kw.items()))
+    if key not in _bulk_cache:
+        _bulk_cache[key] = _mie.tabulated_phase(*_mie.log_normal_bulk_phase(**kw))
+    return _bulk_cache[key]
+
+
+def phase_function(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None):
+    """'iso' | 'rayleigh' | 'hg' (SOS_Aer_phase_func.py:68,79,141); 'mie' (one sphere of radius r, :299);
+    'eva' | 'wildfire' (log-normal ensemble, :398; parameters default to the README's scenarios)."""
     if name == "iso":
         return np.ones(2 * nb_angles), 2 * np.ones((2 * nb_angles, 2 * nb_angles))
     if name == "rayleigh":
         return _azimuth_averaged(lambda c: (3 / 4) * (1 + c * c), mu, mu0)
     if name == "hg":
         return _azimuth_averaged(lambda c: (1 - g * g) / ((1 + g * g - 2 * g * c) ** 1.5), mu, mu0)
-    raise NotImplementedError(
-        "phase function %r needs Mie theory (miepython in the reference), which is not available offline; "
-        "pass pre-built (P0, P) arrays instead" % (name,))
+    if name in ("eva", "wildfire"):
+        kw = dict(_mie.SCENARIOS[name])
+        for k, v in (("wl", lambda0), ("m", indx), ("r_m", r_m), ("sig", sig)):
+            if v:
+                kw[k] = v
+        return _azimuth_averaged(_bulk(name, **kw), mu, mu0)
+    if name == "mie":
+        if not (r and lambda0 and indx):
+            raise ValueError("'mie' needs r, lambda0 and indx")
+        x = 2 * np.pi * r / lambda0
+        mu_d = np.linspace(-1, 1, 6001)
+        return _azimuth_averaged(_mie.tabulated_phase(mu_d, _mie.i_unpolarized(complex(indx), x, mu_d)), mu, mu0)
+    raise ValueError("unknown phase function %r" % (name,))

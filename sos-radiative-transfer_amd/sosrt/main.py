@@ -120,7 +120,7 @@ def SOS_Aer(surface="specular", tol=1e-4, max_orders=256, P_atm=None, P0_atm=Non
             **overrides) -> ColumnResult:
     """One column with the reference's parameter names (spec:19-96).  `surface` selects the file of
     the reference that would be run ('specular' | 'lambertian'); P*/P0* accept pre-built phase
-    arrays (required for the Mie-derived 'mie' / 'eva' / 'wildfire' functions)."""
+    arrays."""
     unknown = set(overrides) - set(DEFAULTS)
     if unknown:
         raise TypeError("unknown parameter(s): %s" % ", ".join(sorted(unknown)))
@@ -128,9 +128,11 @@ def SOS_Aer(surface="specular", tol=1e-4, max_orders=256, P_atm=None, P0_atm=Non
     N, L = int(p["nb_angles"]), int(p["nb_layers"])
     mu = direction_grid(N)
     if P_atm is None or P0_atm is None:
-        P0_atm, P_atm = phase_function(p["atm_phase_fun"], N, mu, p["mu0"], p["g_atm"])
+        P0_atm, P_atm = phase_function(p["atm_phase_fun"], N, mu, p["mu0"], p["g_atm"], p["r_atm"], p["lambda0_atm"],
+                                       p["indx_atm"], p["r_m_atm"], p["sig_atm"])
     if P_aer is None or P0_aer is None:
-        P0_aer, P_aer = phase_function(p["aer_phase_fun"], N, mu, p["mu0"], p["g_aer"])
+        P0_aer, P_aer = phase_function(p["aer_phase_fun"], N, mu, p["mu0"], p["g_aer"], p["r_aer"], p["lambda0_aer"],
+                                       p["indx_aer"], p["r_m_aer"], p["sig_aer"])
     r = SOS_Aer_batch(p["mu0"], p["tauStar_aer"], p["grd_alb"], tauStar_atm=p["tauStar_atm"], alb_atm=p["alb_atm"],
                       alb_aer=p["alb_aer"], z0=p["z0"], z_up=p["z_up"], z_down=p["z_down"], nb_layers=L, nb_angles=N,
                       P_atm=P_atm, P_aer=P_aer, P0_atm=np.asarray(P0_atm)[None], P0_aer=np.asarray(P0_aer)[None],

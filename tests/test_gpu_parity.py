@@ -181,8 +181,8 @@ def test_SOS_Aer_call_surface():
     assert r.I[0, 32:].max() == pytest.approx(0.6862303878773028, rel=1e-12)
     with pytest.raises(TypeError):
         SOS_Aer(nb_layer=3)
-    with pytest.raises(NotImplementedError):
-        SOS_Aer(nb_layers=20, nb_angles=16)            # shipped aerosol is 'eva': needs Mie inputs
+    full = SOS_Aer(nb_layers=40, nb_angles=32, grd_alb=0.15)     # the shipped EVA aerosol (own Mie series: parity unpinned)
+    assert full.status == 0 and full.n >= 2 and np.isfinite(full.I).all() and (full.I[0, 33:] > 0).all()
 
 
 # ----------------------------------------------------------------------------------------------

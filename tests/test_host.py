@@ -91,8 +91,8 @@ def test_input_builders():
             P0, P = inputs.phase_function(name, N, mu, mu0, g)
             assert_close(P0, d[nm + "_P0"], 1e-14, nm)
             assert_close(P, d[nm + "_P"], 1e-14, nm)
-    with pytest.raises(NotImplementedError):
-        inputs.phase_function("eva", 8, inputs.direction_grid(8), 0.5)
+    with pytest.raises(ValueError):
+        inputs.phase_function("nope", 8, inputs.direction_grid(8), 0.5)
     d = np.load(golden("g5_tau_profile.npz")[0])
     for i in range(int(d["n"])):
         ta, tr, z0, zu, zd, L = d["p%d" % i]
@@ -107,3 +107,35 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "sos_oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_mie_series_and_log_normal_ensemble():
+    """Own Mie series (miepython is absent: parity unpinned) against published values and identities."""
+    from sosrt import mie
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    # Bohren & Huffman appendix A test case: m = 1.55, x = 2 pi 0.525 / 0.6328
+    qe, qs, qb, g = mie.efficiencies(1.55 + 0j, 2 * np.pi * 0.525 / 0.6328)
+    assert (round(qe, 5), round(qs, 5), round(qb, 5), round(g, 5)) == (3.10543, 3.10543, 2.92534, 0.63314)
+    # Rayleigh limit: p ~ 1 + mu^2
+    mu = np.linspace(-1, 1, 9)
+    p = mie.i_unpolarized(1.5 + 0j, 0.02, mu)
+    assert np.allclose(p / p[4], 1 + mu ** 2, rtol=2e-3)
+    th = np.linspace(0, np.pi, 20001)
+    for m, x in ((1.44 + 0j, 5.0), (1.7 + 0.03j, 2.0), (1.33 + 0.1j, 30.0)):
+        qe, qs, _, g = mie.efficiencies(m, x)
+        S1, _ = mie.amplitudes(m, x, np.array([1.0]))
+        assert qe == pytest.approx(4 / x ** 2 * S1[0].real, rel=1e-12)            # optical theorem
+        pv = mie.i_unpolarized(m, x, np.cos(th))
+        assert trapz(pv * np.sin(th), th) * 2 * np.pi == pytest.approx(qs / qe, rel=1e-5)   # integrates to the albedo
+        assert trapz(pv * np.cos(th) * np.sin(th), th) * 2 * np.pi / (qs / qe) == pytest.approx(g, rel=1e-5)
+    assert mie.efficiencies(1.5 + 0j, 2000.0)[0] == pytest.approx(2.0, abs=0.03)    # extinction paradox
+    # ensemble phase functions of the reference's two scenarios: normalisations of phase:103,131
+    N = 16
+    mug = inputs.direction_grid(N)
+    for name in ("eva", "wildfire"):
+        P0, P = inputs.phase_function(name, N, mug, 0.5)
+        assert trapz(P0, mug) == pytest.approx(2.0, rel=1e-12)
+        assert np.allclose(trapz(P, mug, axis=0), 4.0, rtol=1e-12)
+        assert (P > 0).all() and (P0 > 0).all()
+    P0e, _ = inputs.phase_function("eva", N, mug, 0.5)
+    assert P0e[:N].sum() > 2 * P0e[N:].sum()        # micron-size sulphate scatters forward: sunlight keeps going down
