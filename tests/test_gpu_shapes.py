@@ -91,3 +91,28 @@ def test_saved_orders_on_device_path_and_stats():
     assert n[1] == int(g["n"])
     assert_close(I[1], g["I"], RTOL, "C1 column through the device path")
     s.close()
+
+
+def test_forcing_and_critical_albedo_drivers():
+    """crit:377-410 on top of the batched solve; fluxes checked against the oracle's."""
+    from sosrt import forcing
+    L, N = 60, 64      # at N = 32 the reference itself raises IndexError for the bright columns of this test
+    mu = inputs.direction_grid(N)
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, 0.5)
+    P0r, Pr = inputs.phase_function("hg", N, mu, 0.5, 0.7)
+    kw = dict(nb_layers=L, nb_angles=N, z_up=40, z_down=12, phases=(P0a, Pa, P0r, Pr))
+    taer, walb = [0.05, 0.3], [0.95, 0.8]
+    got = forcing.toa_net_flux(0.5, 0.124, taer, 0.15, 1.0, walb, **kw)
+    for b in range(2):
+        col = O.make_column(0.5, 120, 40, 12, L, 0.124, taer[b], 0.15, 1.0, walb[b], N, P0a, Pa, P0r, Pr)
+        I = O.solve_column(col, literal=False).I
+        fd, fu = O.fluxes(I, mu, col.tau, N, 0.5, 0.15, beam_norm="crit")
+        assert got[b] == pytest.approx(-fd[0] - fu[0], rel=1e-10)
+    dF = forcing.radiative_forcing(0.5, 0.124, taer, 0.15, 1.0, walb, **kw)
+    assert dF.shape == (2,) and np.all(np.isfinite(dF)) and np.all(dF != 0)
+    # a conservative bright aerosol sends more light back (less net flux in); a dark one absorbs
+    bright = forcing.radiative_forcing(0.5, 0.124, [0.3], 0.15, 1.0, [1.0], **kw)[0]
+    dark = forcing.radiative_forcing(0.5, 0.124, [0.3], 0.15, 1.0, [0.3], **kw)[0]
+    assert bright < dark
+    wc = forcing.critical_albedo(0.5, 0.124, [0.1, 0.3], 0.15, 1.0, **kw)
+    assert wc.shape == (2,) and np.all((wc > 0) & (wc < 1))
