@@ -41,7 +41,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     const int bm0 = tile * BM, bn0 = blockIdx.y * GEMM_BN;
 
     // the row this thread stages, its coefficients; skip the tile when every column it touches has converged
-    const int arow = tid >> 2, akq = (tid & 3) * 8;
+    const int arow = tid >> 2, akq = (tid & 3) * (GEMM_KC / 4);
     int grow = -1;
     if (arow < BM && bm0 + arow < nrows) grow = rows ? rows[bm0 + arow] : bm0 + arow;
     if (g.active) {
@@ -61,22 +61,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
 
-    const int bk = tid >> 3, bc = (tid & 7) * 16;
+    constexpr int BQ = GEMM_KC * GEMM_BN / 256 / 2;      // double2 per thread of a W chunk
+    constexpr int AQ = GEMM_KC / 8;                       // double2 per thread of an A chunk
+    const int bk = tid / (GEMM_BN / (2 * BQ)), bc = (tid % (GEMM_BN / (2 * BQ))) * 2 * BQ;
     const int fr = lane & 15, fk = lane >> 4;
     const int nck = Dp / GEMM_KC;                 // chunks per pass
     const int ntot = slab ? 2 * nck : nck;
 
     // Register staging as plain named values (arrays passed through lambdas end up in scratch).  The A
     // operand (In_1, from HBM) is staged two chunks ahead, the W operand (L2-resident) one chunk ahead.
-    struct StageA { double2 a[4]; };
-    StageA s0, s1;
+    struct StageA { double2 a[AQ]; };
+    StageA s0;
     double2 sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;     // named: an array here ends up in scratch
     // global -> registers for chunk c (clamped: every call issues the same loads)
 #define SOSRT_GLOAD_A(ST, c_)                                                                             \
     {                                                                                                     \
         const int cc_ = min((c_), ntot - 1);                                                              \
         const int kc_ = (cc_ >= nck ? cc_ - nck : cc_) * GEMM_KC;                                         \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+        _Pragma("unroll") for (int q = 0; q < AQ; ++q) {                                                  \
             const int k0_ = kc_ + akq + 2 * q;                                                            \
             ST.a[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + k0_)          \
                                                  : make_double2(0, 0);                                    \
@@ -91,18 +93,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
         const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bn0 + bc;                                     \
         sb0 = *reinterpret_cast<const double2*>(Wp_); sb1 = *reinterpret_cast<const double2*>(Wp_ + 2);    \
         sb2 = *reinterpret_cast<const double2*>(Wp_ + 4); sb3 = *reinterpret_cast<const double2*>(Wp_ + 6); \
+        if (BQ > 4) {                                                                                     \
         sb4 = *reinterpret_cast<const double2*>(Wp_ + 8); sb5 = *reinterpret_cast<const double2*>(Wp_ + 10); \
-        sb6 = *reinterpret_cast<const double2*>(Wp_ + 12); sb7 = *reinterpret_cast<const double2*>(Wp_ + 14); \
+        sb6 = *reinterpret_cast<const double2*>(Wp_ + 12); sb7 = *reinterpret_cast<const double2*>(Wp_ + 14); } \
     }
 #define SOSRT_LSTORE(ST, c_)                                                                              \
     {                                                                                                     \
         const double cf_ = (c_) >= nck ? coef_r : coef_a;                                                 \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                     \
+        _Pragma("unroll") for (int q = 0; q < AQ; ++q)                                                    \
             *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                                 \
                 make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                           \
         double2* sbp_ = reinterpret_cast<double2*>(&sB[bk * B_LD + bc]);                                  \
         sbp_[0] = sb0; sbp_[1] = sb1; sbp_[2] = sb2; sbp_[3] = sb3;                                       \
-        sbp_[4] = sb4; sbp_[5] = sb5; sbp_[6] = sb6; sbp_[7] = sb7;                                       \
+        if (BQ > 4) { sbp_[4] = sb4; sbp_[5] = sb5; sbp_[6] = sb6; sbp_[7] = sb7; }                       \
     }
     auto compute = [&]() {
 #pragma unroll
@@ -121,21 +124,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     };
 
     SOSRT_GLOAD_A(s0, 0);
-    SOSRT_GLOAD_A(s1, 1);
     SOSRT_GLOAD_B(0);
-    for (int c = 0; c < ntot; c += 2) {
+    for (int c = 0; c < ntot; ++c) {
         __syncthreads();                 // previous chunk consumed
         SOSRT_LSTORE(s0, c);
         __syncthreads();
-        SOSRT_GLOAD_A(s0, c + 2);
+        SOSRT_GLOAD_A(s0, c + 1);
         SOSRT_GLOAD_B(c + 1);
-        compute();
-        if (c + 1 >= ntot) break;
-        __syncthreads();
-        SOSRT_LSTORE(s1, c + 1);
-        __syncthreads();
-        SOSRT_GLOAD_A(s1, c + 3);
-        SOSRT_GLOAD_B(c + 2);
         compute();
     }
 #undef SOSRT_GLOAD_A
@@ -159,19 +154,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_jn_gemm(GemmArgs g) {
-    __shared__ double sA[GEMM_BM * A_LD];
+__global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
+    __shared__ double sA[16 * (GEMM_RT > 2 ? GEMM_RT : 2) * A_LD];
     __shared__ double sB[GEMM_KC * B_LD];
     __shared__ int s_any;
-    const int tiles_main = (g.n_main + GEMM_BM - 1) / GEMM_BM;
-    if ((int)blockIdx.x < tiles_main) gemm_tile<4, false>(g, sA, sB, &s_any, blockIdx.x);
+    const int tiles_main = (g.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT);
+    if ((int)blockIdx.x < tiles_main) gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, blockIdx.x);
     else gemm_tile<2, true>(g, sA, sB, &s_any, (int)blockIdx.x - tiles_main);
 }
 
 }  // namespace
 
 void launch_gemm(hipStream_t s, const GemmArgs& a) {
-    const int tiles = (a.n_main + GEMM_BM - 1) / GEMM_BM + (a.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);
+    const int tiles = (a.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT) + (a.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);
     if (tiles <= 0) return;
     dim3 grid(tiles, (a.D + GEMM_BN - 1) / GEMM_BN);
     hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), 0, s, a);

@@ -67,7 +67,15 @@ struct Conv {
     double tol;
 };
 
-constexpr int GEMM_BM = 64, GEMM_BN = 128, GEMM_KC = 32;
+constexpr int GEMM_BM = 64, GEMM_BN = 128, GEMM_KC = 16;
+#ifndef SOSRT_GEMM_RT
+#define SOSRT_GEMM_RT 4
+#endif
+#ifndef SOSRT_GEMM_WPS
+#define SOSRT_GEMM_WPS 3
+#endif
+constexpr int GEMM_RT = SOSRT_GEMM_RT;     // MFMA row tiles per wave of the plain-row workgroups
+constexpr int GEMM_WPS = SOSRT_GEMM_WPS;   // waves per SIMD the register budget is set for
 
 // Transport rows are processed in chunks of TC: the loads of the next chunks are in flight while
 // the current one is computed, the per-row source terms of a chunk are independent
