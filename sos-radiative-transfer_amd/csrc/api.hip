@@ -74,7 +74,8 @@ struct sosrt_handle {
     int use_etab = 1;
     // convergence
     int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr;
-    int transport_mode = 1;              // 1: wave-independent fast kernel (+ repair), 0: general kernel
+    int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel (+ repair)
+    bool ring_ok = false;
     bool fast_ok = false;
     double* d_ratio = nullptr;
     int* h_poll = nullptr;               // pinned [2]
@@ -176,7 +177,11 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;
     h->gpu = device >= 0;
     if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
-    if (const char* ev = getenv("SOSRT_TRANSPORT")) h->transport_mode = (strcmp(ev, "general") == 0) ? 0 : 1;
+    if (const char* ev = getenv("SOSRT_TRANSPORT"))
+        h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : 1);
+    if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
+    if (const char* ev = getenv("SOSRT_RING_LOADERS")) g_ring_loaders = atoi(ev);
+    if (const char* ev = getenv("SOSRT_RING_DEBUG")) g_ring_debug = atoi(ev);   // timing experiments, see transport_ring.hip
     Grid& g = h->g;
     g.L = L; g.N = N; g.D = 2 * N;
     g.Dp = (g.D + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
@@ -298,6 +303,7 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
         h->g.nsmall = (int)h->plan.small_lanes.size();
         if (h->g.nsmall)
             HIPCHK(hipMemcpy(h->d_small, h->plan.small_lanes.data(), h->g.nsmall * sizeof(int), hipMemcpyHostToDevice));
+        h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
     }
     return 0;
 }
@@ -428,10 +434,11 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     launch_smallmu(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, h->d_desc, nullptr);
     prof_end(h, SOSRT_K_SMALLMU);
     prof_begin(h, SOSRT_K_TRANSPORT);
-    if (h->transport_mode == 1 && h->fast_ok) {
+    if (h->transport_mode >= 1 && h->fast_ok) {
         launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E);
         HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
-        launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 1);
+        launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E,
+                         (h->transport_mode == 2 && h->ring_ok) ? 3 : 1);
         if (h->N - 3 > 61)
             launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 2);
     } else {
@@ -491,7 +498,8 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
 
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr);
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
-    const bool fast = h->transport_mode == 1 && h->fast_ok;
+    const bool fast = h->transport_mode >= 1 && h->fast_ok;
+    const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) launch_attenuation(s, g, B, d_tau, h->d_E);
     if (fast) HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), s));
     double* In_1 = h->d_InA;
@@ -527,7 +535,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         prof_begin(h, SOSRT_K_TRANSPORT);
         double* sv_n = d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr;
         if (fast) {
-            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 1);
+            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, fast_mode);
             if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
                 launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 2);
         } else {

@@ -1,0 +1,588 @@
+// k_transport_ring: one order of transport (spec:326-449), rows streamed through an LDS ring.
+//
+// Same arithmetic and the same lane mapping as k_transport_fast (thread j = downward direction j,
+// then upward direction N+j; the mu -> 0 treatments live in the last / first wave), but the rows
+// of Jn, of the attenuation table and of the running total do not come through registers of the
+// computing waves.  A workgroup is  nwc = ceil(N/64) computing waves + NWL loader waves.  The
+// loaders copy chunks of TC rows into an LDS ring of NS slots with `buffer_load_dwordx4 ... lds`
+// (1 KiB per wave-instruction, no VGPR destination), R = NS-1 chunks ahead of the computing waves;
+// the computing waves read a chunk from LDS, run the recurrence and store.
+//
+// Why: a lone column is latency-bound (a wave may have 63 vector-memory operations outstanding,
+// loads and stores together, and with 8-byte lanes that is 32 KiB).  Here the loads in flight are
+// R chunks of 24 KiB per column and they do not share the counter with the stores.
+//
+// Chunk sequence q = 0 .. 2 NCH-1: the NCH chunks of the downward sweep (rows ascending, lanes
+// [0, N)), then the NCH chunks of the upward sweep (rows descending, lanes [N, 2N)); the loaders
+// run across the seam, so the upward sweep starts with its first chunks already in LDS.
+//
+// Protocol (one s_barrier per chunk, raw: __syncthreads() would drain the loads in flight):
+//   every loader carries 1/NWL of the rows of every chunk.  In iteration q it issues its part of
+//   chunk q+R into slot (q+R) mod NS -- the slot read in iteration q-1 -- and waits with a counted
+//   vmcnt until only its parts of the younger chunks are outstanding; then the barrier.
+//   computing waves in iteration q read slot q mod NS (landed before the barrier that ended
+//   iteration q-1), wait lgkmcnt(0) and join the barrier.
+#include <type_traits>
+
+#include "../../include/sosrt.h"
+#include "kernels.hpp"
+#include "transport_util.hpp"
+
+namespace sosrt {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr size_t kRingLdsBytes = 152 * 1024;               // of the 160 KiB of a CU
+
+template <int CNT>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+}
+// workgroup barrier that leaves vector-memory operations in flight
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool ACC, bool SAVED, int PIECES>
+__global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int NWL, int dbg) {
+    const int b = blockIdx.x;
+    if (ACC && !a.cv.active[b]) return;
+    const Grid& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int L = g.L, N = g.N, D = g.D;
+    const int nwc = (N + 63) >> 6;                             // computing waves
+    const bool loader = wid >= nwc;
+    const int lid = wid - nwc;
+    const bool w0 = wid == 0 && !(dbg & 8);
+    const bool wl = wid == ((N - 1) >> 6) && !(dbg & 4);                     // the wave that holds the mu -> 0- lanes
+    auto stamp = [&](int i) {
+        if (a.stamps && (tid == 0 || tid == 64)) a.stamps[((size_t)b * 2 + (tid >> 6)) * 8 + i] = clock64();
+    };
+    stamp(0);
+    constexpr int NARR = ACC ? 3 : 2;                          // Jn, attenuation, [running total]
+    constexpr int RS = 128 * PIECES;                           // doubles per LDS row (one half row of the field)
+    constexpr int SLOT = NARR * TC * RS;                       // doubles per ring slot
+    constexpr int IPC = NARR * TC * PIECES;                    // wave-instructions per chunk
+    extern __shared__ double sm[];
+    double* ring = sm;                                         // [NS][NARR][TC][RS]
+    double* s_sfc = ring + (size_t)NS * SLOT;                  // [blockDim] surface row by downward lane m
+    double* s_red = s_sfc + blockDim.x;                        // [nw + 1]
+    double* s_hd = s_red + (blockDim.x >> 6) + 2;              // [L + 1] half layer thicknesses: hd[t] = (tau[t] - tau[t-1]) / 2
+    double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
+    double* s_x = s_S + (size_t)g.nsmall * L;                  // [TC][64] rows of the wave that holds a mu -> 0 neighbourhood
+    double* s_prmu = s_x + TC * 64;                            // [16] 1/mu of the first upward directions
+    __shared__ FixTab s_fix[kMaxZones];
+    __shared__ int s_flag[2];                                  // [0] redo with the general kernel, [1] IndexError
+    const ColDesc* __restrict__ dg = a.desc + b;
+    const int nz = dg->nz;
+    const int zend0 = nz > 1 ? dg->r1[0] : -9, zend1 = nz > 2 ? dg->r1[1] : -9;
+    const int zbeg1 = nz > 1 ? dg->r0[1] : -9, zbeg2 = nz > 2 ? dg->r0[2] : -9;
+    const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
+    const int surface = dg->surface;
+    const double rho = dg->rho;
+    const int fbytes = L * D * 8, RB = D * 8;
+    // dbg (timing experiments only, results are wrong): 1 drops the loads, 2 the stores (zero-sized descriptors)
+    const int lbytes = (dbg & 1) ? 0 : fbytes, sbytes = (dbg & 2) ? 0 : fbytes;
+    const __amdgpu_buffer_rsrc_t rJ = make_rsrc(a.Jn + (size_t)b * L * D, lbytes);
+    const __amdgpu_buffer_rsrc_t rE = make_rsrc(a.Etab + (size_t)b * L * D, lbytes);
+    const __amdgpu_buffer_rsrc_t rIn = make_rsrc(a.In + (size_t)b * L * D, sbytes);
+    const __amdgpu_buffer_rsrc_t rIl = make_rsrc(ACC ? a.I + (size_t)b * L * D : a.In, ACC ? lbytes : 0);
+    const __amdgpu_buffer_rsrc_t rI = make_rsrc(ACC ? a.I + (size_t)b * L * D : a.In, ACC ? sbytes : 0);
+    const __amdgpu_buffer_rsrc_t rS = make_rsrc(SAVED ? a.saved + (size_t)b * a.saved_col_stride : a.In, SAVED ? sbytes : 0);
+    const int NCH = (L + TC - 1) / TC, NQ = 2 * NCH, R = NS - 1;
+    const bool valid = tid < N;
+    const int tidc = valid ? tid : N - 1;
+    auto touches = [&](int lo, int hi) {
+        return (zend0 >= lo && zend0 <= hi) || (zend1 >= lo && zend1 <= hi) || (zbeg1 >= lo && zbeg1 <= hi) ||
+               (zbeg2 >= lo && zbeg2 <= hi);
+    };
+    double rdn_v = 0, rdn_i = 1, rup_v = 0, rup_i = 1;
+    double sfc_own = 0;
+
+    // ------------------------------- loader side -------------------------------
+    // chunk q -> slot q mod NS; rows clamped at the ragged ends exactly as the computing side expects.
+    // Every loader carries its share of every chunk (rows u = lid mod NWL): the loads of a chunk are
+    // issued in 1/NWL of the time, and that time is on the critical path of an iteration.
+    auto issue = [&](int q) {
+        const bool up = q >= NCH;
+        const int j = up ? q - NCH : q;
+        double* dst = ring + (size_t)(q % NS) * SLOT;
+        const int half = up ? N * 8 : 0;
+        const int vo = lane * 16;
+#pragma unroll
+        for (int u = 0; u < TC; ++u) {
+            if ((u & (NWL - 1)) != lid) continue;
+            const int row = up ? max(L - 1 - j * TC - u, 0) : min(j * TC + u, L - 1);
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                const int so = row * RB + half + p * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * RS + p * 128), 16, vo, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * RS + p * 128), 16, vo, so, 0, 0);
+                if (ACC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rIl, (lds_ptr_t)(dst + (2 * TC + u) * RS + p * 128), 16, vo, so, 0, 0);
+            }
+        }
+    };
+    // wait until at most the `w` youngest chunks are still in flight (vmcnt is an immediate: the
+    // count is rounded down to a multiple of 4, which only waits a little longer)
+    auto wait_chunks = [&](int w) {
+        const int n = min(w * (IPC / NWL), 60) >> 2;
+        switch (n) {
+            case 0: wait_vm<0>(); break;
+            case 1: wait_vm<4>(); break;
+            case 2: wait_vm<8>(); break;
+            case 3: wait_vm<12>(); break;
+            case 4: wait_vm<16>(); break;
+            case 5: wait_vm<20>(); break;
+            case 6: wait_vm<24>(); break;
+            case 7: wait_vm<28>(); break;
+            case 8: wait_vm<32>(); break;
+            case 9: wait_vm<36>(); break;
+            case 10: wait_vm<40>(); break;
+            case 11: wait_vm<44>(); break;
+            case 12: wait_vm<48>(); break;
+            case 13: wait_vm<52>(); break;
+            case 14: wait_vm<56>(); break;
+            default: wait_vm<60>(); break;
+        }
+    };
+    auto loader_phase = [&](int qa, int qb) {
+        for (int q = qa; q < qb; ++q) {
+            if (q + R < NQ && !(dbg & 16)) issue(q + R);
+            if (q + 1 < NQ) wait_chunks(min(q + R, NQ - 1) - (q + 1));      // chunk q+1 has landed
+            wg_barrier();
+        }
+    };
+    // Start-up: the loaders put the first R chunks in flight at once; meanwhile the computing waves
+    // fill the small per-column tables.  They live in LDS because inside the sweeps a computing wave
+    // must never wait for a global load: the wait would also cover its stores (one counter).
+    const int ncomp = nwc * 64;
+    if (loader) {
+        for (int q = 0; q < min(R, NQ); ++q) issue(q);
+    } else {
+        for (int zz = 0; zz < kMaxZones; ++zz) {
+            const double* src = reinterpret_cast<const double*>(&g.fix[dg->fixtab[zz]]);
+            double* dst = reinterpret_cast<double*>(&s_fix[zz]);
+            for (int i = tid; i < (int)(sizeof(FixTab) / sizeof(double)); i += ncomp) dst[i] = src[i];
+        }
+        if (tid < 2) s_flag[tid] = 0;
+        const double* __restrict__ tau = a.tau + (size_t)b * L;
+        for (int t = tid; t <= L; t += ncomp) s_hd[t] = (t == 0 || t == L) ? 0.0 : (tau[t] - tau[t - 1]) * 0.5;
+        if (tid < 16) s_prmu[tid] = (tid > 0 && tid < N) ? 1.0 / g.mu[N + tid] : 0.0;
+        const double* __restrict__ In0 = a.In + (size_t)b * L * D;
+        for (int i = tid; i < g.nsmall * L; i += ncomp) {
+            const int k = i / L, t = i - k * L;
+            s_S[i] = In0[(size_t)t * D + g.small_lanes[k]];
+        }
+    }
+    __syncthreads();                                            // (drains the loaders once: chunks 0 .. R-1 have landed)
+
+    // The loader waves run their whole stream in this one branch and meet the computing waves at every
+    // barrier; keeping the two roles on disjoint paths also keeps the compiler from ordering the
+    // computing waves' LDS reads (and with them their stores) behind loads they never issue.
+    const int seam_barriers = surface == SOSRT_SURFACE_NONE ? 0 : (surface == SOSRT_SURFACE_SPECULAR ? 1 : 3);
+    double Bv = 0;
+    if (loader) {
+        loader_phase(0, NCH);
+        for (int i = 0; i < seam_barriers; ++i) wg_barrier();
+        loader_phase(NCH, NQ);
+        wait_vm<0>();
+    } else {
+    stamp(1);
+    const double mu_up = (valid && tid > 0) ? g.mu[N + tidc] : 1.0;   // loaded here: no global load may follow the first store
+    // Transposed work items for the two mu -> 0 treatments: lane = 8 * (row of the chunk) + (position).
+    const int uT = lane >> 3, pT = lane & 7;
+    const double muT = (pT + 1 < N) ? g.mu[N + pT + 1] : 1.0;          // upward direction N + pT + 1
+    const double* xrow = s_x + uT * 64;
+    // =============================== downward ===============================
+    {
+        const int m = tidc;
+        const int vo = m * 8;
+        const double mu = g.mu[m];
+        const bool tr = valid && m <= N - 2;
+        const bool small = tr && fabs(mu) < kMuThreshold;       // spec:333
+        const bool stdl = tr && !small;
+        const double nrmu = stdl ? -1.0 / mu : 0.0;
+        const bool has_small = wl && g.nsmall > 0;
+        double Dv = 0, Jprev = 0;
+        double c[kFixMaxSrc] = {0, 0, 0, 0, 0};
+        double cT[kFixMaxSrc] = {0, 0, 0, 0, 0};               // row pT of the table: work item (uT, pT) rewrites direction N-1-pT
+        int sl[kFixMaxSrc] = {0, 0, 0, 0, 0};
+        int nfx = 0;
+        bool fixlane = false;
+        auto load_fix = [&](int zz) {
+            const FixTab& ft = s_fix[zz];
+            nfx = zz == 0 ? nfix0 : (zz == 1 ? nfix1 : nfix2);
+            const int ns = nfx < 2 ? 2 : (nfx < kFixMaxSrc ? nfx : kFixMaxSrc);     // In_limit:118-141
+            fixlane = valid && nfx > 0 && m >= N - nfx;
+            const int i = fixlane ? N - 1 - m : 0;
+            const int s0 = nfx < 2 ? N - nfx - 2 : N - nfx - ns;
+#pragma unroll
+            for (int q = 0; q < kFixMaxSrc; ++q) {
+                c[q] = (fixlane && q < ns) ? ft.C[i * ns + min(q, ns - 1)] : 0.0;
+                cT[q] = (pT < nfx && q < ns) ? ft.C[pT * ns + min(q, ns - 1)] : 0.0;
+                sl[q] = (s0 + min(q, ns - 1)) & 63;
+            }
+        };
+        if (wl) load_fix(0);
+        const int sbase = small ? (m - g.small_lanes[0]) * L : 0;   // the small lanes are consecutive directions
+        int t0 = 0, q = 0;
+        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) {
+            constexpr bool SP = decltype(special_t)::value;
+            double cc[TC], v[TC], Sc[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) Sc[u] = 0;
+            if (has_small) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const double sv = s_S[sbase + min(t0 + u, L - 1)];
+                    Sc[u] = small ? sv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = SP ? min(t0 + u, L - 1) : t0 + u;
+                const double hk = s_hd[t];
+                const double Jp = u == 0 ? Jprev : Jc[u - 1];
+                cc[u] = (hk * nrmu) * (Jp * Ec[u] + Jc[u]);
+            }
+            if (!SP) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    Dv = Dv * Ec[u] + cc[u];
+                    v[u] = Dv;
+                }
+                if (has_small) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) v[u] += Sc[u];
+                }
+                // In_limit:113-141 as a linear map of the source lanes.  Up to 8 rewritten directions: the
+                // chunk goes through LDS and work item (uT, pT) does row uT, direction N-1-pT -- one pass for
+                // the 8 rows instead of 8 passes of cross-lane reads.
+                const bool tfix = wl && nfx > 0 && nfx <= 8;
+                if (tfix) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) s_x[u * 64 + lane] = v[u];
+                    double acc = 0;
+#pragma unroll
+                    for (int k = 0; k < kFixMaxSrc; ++k) acc += cT[k] * xrow[sl[k]];
+                    const int mT = N - 1 - pT;
+                    const double IcT = ACC ? slot[(2 * TC + uT) * RS + max(mT, 0)] : 0.0;
+                    if (pT < nfx) {
+                        const int voT = (t0 + uT) * RB + mT * 8;
+                        bstore(rIn, voT, 0, acc);
+                        if (ACC) bstore(rI, voT, 0, IcT + acc);
+                        if (SAVED) bstore(rS, voT, 0, acc);
+                    }
+                } else if (wl && nfx > 0) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        double acc = 0;
+#pragma unroll
+                        for (int k = 0; k < kFixMaxSrc; ++k) acc += c[k] * readlane_f64(v[u], sl[k]);
+                        v[u] = fixlane ? acc : v[u];
+                    }
+                }
+                if (valid && !(tfix && fixlane)) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        const int so = (t0 + u) * RB;
+                        bstore(rIn, vo, so, v[u]);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
+                        if (SAVED) bstore(rS, vo, so, v[u]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 + u;
+                    if (wl && (t == zbeg1 || t == zbeg2)) load_fix(t == zbeg1 ? 1 : 2);
+                    const double Dn = Dv * Ec[u] + cc[u];
+                    double x = has_small ? Dn + Sc[u] : Dn;
+                    if (wl && nfx > 0) {
+                        double acc = 0;
+#pragma unroll
+                        for (int k = 0; k < kFixMaxSrc; ++k) acc += c[k] * readlane_f64(x, sl[k]);
+                        x = fixlane ? acc : x;
+                    }
+                    v[u] = x;
+                    const bool zone_end = t == zend0 || t == zend1;     // the next zone starts from the final row (spec:359,378)
+                    Dv = t < L ? (zone_end ? (stdl ? x : 0.0) : Dn) : Dv;
+                    if (valid && t < L) {
+                        const int so = t * RB;
+                        bstore(rIn, vo, so, x);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + x);
+                        if (SAVED) bstore(rS, vo, so, x);
+                    }
+                }
+            }
+            if (t0 + TC >= L) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u)
+                    if (t0 + u == L - 1) { sfc_own = v[u]; rdn_v = v[u]; rdn_i = Ic[u] + v[u]; }
+            }
+            Jprev = Jc[TC - 1];
+            t0 += TC;
+        };
+        for (; q < NCH; ++q) {
+            const double* sp = ring + (size_t)(q % NS) * SLOT + tid;
+            double Jc[TC], Ic[TC], Ec[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                Jc[u] = sp[(0 * TC + u) * RS];
+                Ec[u] = sp[(1 * TC + u) * RS];
+                Ic[u] = ACC ? sp[(2 * TC + u) * RS] : 0.0;
+            }
+            // general body: zone boundaries, and the last chunk (its final row feeds the surface and the test)
+            if (t0 + TC >= L || touches(t0, t0 + TC - 1)) process(std::true_type{}, sp - tid, Jc, Ic, Ec);
+            else process(std::false_type{}, sp - tid, Jc, Ic, Ec);
+            wg_barrier();
+        }
+    }
+
+    stamp(2);
+    // =============================== surface ===============================
+    if (surface != SOSRT_SURFACE_NONE) {
+        if (valid) s_sfc[tid] = sfc_own;
+        wg_barrier();
+    }
+    if (surface == SOSRT_SURFACE_SPECULAR) {
+        Bv = valid ? rho * s_sfc[N - 1 - tid] : 0.0;                // spec:397
+    } else if (surface == SOSRT_SURFACE_LAMBERTIAN) {
+        // -2 rho trapz(In[L-1, rev] mu[rev], mu[rev]), rev = N-2 .. 0   (lam:399), descending abscissae
+        double term = 0;
+        if (tid <= N - 3) {
+            const int k0 = N - 2 - tid, k1 = k0 - 1;
+            const double x0 = g.mu[k0], x1 = g.mu[k1];
+            term = (x1 - x0) * (s_sfc[k1] * x1 + s_sfc[k0] * x0) / 2;
+        }
+        double ws = wave_sum_(term);
+        wg_barrier();
+        if (lane == 0) s_red[tid >> 6] = ws;
+        wg_barrier();
+        double S = 0;
+        for (int i = 0; i < nwc; ++i) S += s_red[i];
+        Bv = -2 * rho * S;
+    }
+
+    stamp(3);
+    // =============================== upward ===============================
+    {
+        const int mj = N + tidc;
+        const int vo = mj * 8;
+        const bool tr = valid && tid > 0;
+        const double mu = mu_up;
+        const double prmu = tr ? 1.0 / mu : 0.0;
+        const int last_cand = min(N - 3, 61);
+        bool notfound = false;
+        double U = Bv, Jnext = 0;
+        // spec:401-409 for one row held across wave 0: x is the raw row, returns the blended value
+        auto blend = [&](double x) {
+            const double x1 = lane_up1(x), x2 = lane_up1(x1);
+            const bool stop = lane >= 1 && lane <= last_cand && !(fabs((x - x1) - (x1 - x2)) > 0.0001);
+            const unsigned long long mk = __ballot(stop);
+            const int kf = mk ? __ffsll((long long)mk) : 1;
+            notfound |= (mk == 0);
+            const double r0 = readlane_f64(x, 0), rk = readlane_f64(x, kf);
+            const double w = mu * readlane_f64(prmu, kf);              // mu_m / mu_kf to one rounding
+            const double bl = (1 - w) * r0 + w * rk;
+            return (tr && tid < kf) ? bl : x;
+        };
+        int t0 = L - 1, q = NCH;
+        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) {
+            constexpr bool SP = decltype(special_t)::value;
+            double cc[TC], v[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = SP ? max(t0 - u, 0) : t0 - u;
+                const double hk = s_hd[t + 1];
+                const double Jx = u == 0 ? Jnext : Jc[u - 1];
+                const double src = (hk * prmu) * (Jc[u] + Jx * Ec[u]);
+                // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
+                cc[u] = (SP && (t == zend0 || t == zend1)) ? 0.0 : src;
+            }
+            if (!SP) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    U = U * Ec[u] + cc[u];
+                    v[u] = U;
+                }
+                // spec:401-409.  The search almost always ends within the first few directions: the chunk goes
+                // through LDS and work item (uT, pT) tests candidate k = pT+1 of row uT, then produces direction
+                // N+k of that row (blended below the stop, raw above it) -- one pass for the 8 rows.  A row whose
+                // search goes beyond 8 candidates sends the chunk through the row-by-row path.
+                bool tblend = false;
+                if (w0) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        v[u] = tid == 0 ? Jc[u] : v[u];                  // spec:401
+                        s_x[u * 64 + lane] = v[u];
+                    }
+                    const int k = pT + 1;
+                    const double xa = xrow[k], xb = xrow[k + 1], xc = xrow[k + 2];
+                    const bool stop = (k <= last_cand) & !(fabs((xa - xb) - (xb - xc)) > 0.0001);
+                    const unsigned long long mk = __ballot(stop);
+                    const unsigned bits = (unsigned)(mk >> (8 * uT)) & 0xffu;    // the candidates of this row
+                    tblend = __ballot(bits != 0) == ~0ull;
+                    if (tblend) {
+                        const int kf = __ffs((int)bits) + 1;                     // ks + 1, <= 9
+                        const double r0 = xrow[0], rk = xrow[kf];
+                        const double w = muT * s_prmu[kf];                       // mu_m / mu_kf to one rounding
+                        const double bl = (1 - w) * r0 + w * rk;
+                        const double val = k < kf ? bl : xa;
+                        const double IcT = ACC ? slot[(2 * TC + uT) * RS + k] : 0.0;
+                        if (k < N) {
+                            const int voT = (t0 - uT) * RB + (N + k) * 8;
+                            bstore(rIn, voT, 0, val);
+                            if (ACC) bstore(rI, voT, 0, IcT + val);
+                            if (SAVED) bstore(rS, voT, 0, val);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < TC; ++u) v[u] = blend(v[u]);
+                    }
+                }
+                if (valid && !(tblend && tid >= 1 && tid <= 8)) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        const int so = (t0 - u) * RB;
+                        bstore(rIn, vo, so, v[u]);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
+                        if (SAVED) bstore(rS, vo, so, v[u]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 - u;
+                    const double Un = U * Ec[u] + cc[u];
+                    double x = Un;
+                    if (w0 && t >= 0) x = blend(tid == 0 ? Jc[u] : Un);
+                    v[u] = x;
+                    const bool zone_start = t == zbeg1 || t == zbeg2;   // blended row feeds the zone above
+                    U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
+                    if (valid && t >= 0) {
+                        const int so = t * RB;
+                        bstore(rIn, vo, so, x);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + x);
+                        if (SAVED) bstore(rS, vo, so, x);
+                    }
+                }
+            }
+            if (t0 - TC < 0) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u)
+                    if (t0 - u == 0) { rup_v = v[u]; rup_i = Ic[u] + v[u]; }
+            }
+            Jnext = Jc[TC - 1];
+            t0 -= TC;
+        };
+        for (; q < NQ; ++q) {
+            const double* sp = ring + (size_t)(q % NS) * SLOT + tid;
+            double Jc[TC], Ic[TC], Ec[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                Jc[u] = sp[(0 * TC + u) * RS];
+                Ec[u] = sp[(1 * TC + u) * RS];
+                Ic[u] = ACC ? sp[(2 * TC + u) * RS] : 0.0;
+            }
+            // general body: zone boundaries, and the last chunk (row 0 feeds the convergence test)
+            if (t0 - TC < 0 || touches(t0 - TC + 1, t0)) process(std::true_type{}, sp - tid, Jc, Ic, Ec);
+            else process(std::false_type{}, sp - tid, Jc, Ic, Ec);
+            wg_barrier();
+        }
+        if (w0 && notfound && lane == 0) s_flag[N - 3 <= 61 ? 1 : 0] = 1;
+    }
+    }   // computing waves
+    stamp(4);
+    __syncthreads();
+    stamp(5);
+    if (s_flag[1]) {                                                    // the reference raises IndexError (spec:404)
+        if (tid == 0) {
+            a.cv.status[b] = SOSRT_COL_INDEXERROR;
+            if (ACC) { a.cv.active[b] = 0; a.cv.norders[b] = a.order; atomicSub(a.cv.nactive, 1); }
+        }
+        return;
+    }
+    if (s_flag[0]) {                                                    // let the general kernel redo the upward sweep
+        if (tid == 0) a.cv.redo[b] = 1;
+        return;
+    }
+    if (ACC) {
+        const double ra = block_pymax_(rup_v / rup_i, valid, s_red, 0);
+        const double rb = block_pymax_(rdn_v / rdn_i, valid, s_red, 0);
+        const double r = (rb > ra) ? rb : ra;                               // the outer max() of spec:309
+        if (tid == 0) {
+            a.cv.ratio[b] = r;
+            a.cv.norders[b] = a.order;
+            if (!(r >= a.cv.tol)) {
+                a.cv.active[b] = 0;
+                atomicSub(a.cv.nactive, 1);
+            }
+        }
+    } else if (tid == 0 && a.cv.status) {
+        a.cv.status[b] = SOSRT_COL_OK;
+    }
+}
+
+// doubles of LDS besides the ring: surface row, reduction slots, half thicknesses, small-mu rows
+inline size_t ring_extra_doubles(const Grid& g, int nt) {
+    return (size_t)nt + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 64 + 16;
+}
+
+template <int PIECES>
+void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int NS, int NWL) {
+    const int nt = (int)block.x;
+    const int narr = a.accumulate ? 3 : 2;
+    const size_t shm = ((size_t)NS * narr * TC * 128 * PIECES + ring_extra_doubles(a.g, nt)) * sizeof(double);
+#define SOSRT_RING_LAUNCH(ACC_, SAVED_)                                                                        \
+    do {                                                                                                       \
+        auto kern = k_transport_ring<ACC_, SAVED_, PIECES>;                                                    \
+        static bool big_lds = false;                                                                           \
+        if (!big_lds) {                                                                                        \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)kRingLdsBytes);                                                                   \
+            big_lds = true;                                                                                    \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, NWL, g_ring_debug);                                             \
+    } while (0)
+    if (a.accumulate) {
+        if (a.saved) SOSRT_RING_LAUNCH(true, true);
+        else SOSRT_RING_LAUNCH(true, false);
+    } else {
+        SOSRT_RING_LAUNCH(false, false);
+    }
+#undef SOSRT_RING_LAUNCH
+}
+
+}  // namespace
+
+// The ring needs half rows that are multiples of 16 bytes (N even), at most two 1-KiB pieces per
+// half row, and at least two slots beside the per-column tables.
+bool transport_ring_ok(const Grid& g) {
+    if (g.N % 2 || g.N < 4 || g.N > 256) return false;
+    const int nwc = (g.N + 63) / 64, pieces = g.N <= 128 ? 1 : 2;
+    const size_t slot_bytes = (size_t)3 * TC * 128 * pieces * sizeof(double);
+    return 2 * slot_bytes + ring_extra_doubles(g, (nwc + 4) * 64) * sizeof(double) <= kRingLdsBytes;
+}
+
+// slots: ring depth wanted (2..6); loaders: loader waves per column
+void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots, int loaders) {
+    const int N = a.g.N;
+    const int nwc = (N + 63) / 64;
+    const int pieces = N <= 128 ? 1 : 2;
+    const int narr = a.accumulate ? 3 : 2;
+    int NWL = (loaders == 1 || loaders == 2 || loaders == 4) ? loaders : 2;      // a power of two that divides TC
+    if ((nwc + NWL) * 64 > 512) NWL = 2;
+    const dim3 block((nwc + NWL) * 64);
+    const size_t slot_bytes = (size_t)narr * TC * 128 * pieces * sizeof(double);
+    const size_t extra = ring_extra_doubles(a.g, (int)block.x) * sizeof(double);
+    int NS = slots < 2 ? 2 : slots;
+    while (NS > 2 && NS * slot_bytes + extra > kRingLdsBytes) --NS;
+    if (pieces == 1) launch_p<1>(s, grid, block, a, NS, NWL);
+    else launch_p<2>(s, grid, block, a, NS, NWL);
+}
+
+}  // namespace sosrt

@@ -16,9 +16,10 @@ from util import RTOL, assert_close, column_case, g1_case, golden, oracle_column
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fast", "general"])
+@pytest.fixture(params=["fast", "ring", "general"])
 def transport_mode(request, monkeypatch):
-    """Both transport kernels: the wave-independent one (+ repair) and the general LDS-exchange one."""
+    """The transport kernels: the wave-independent one (+ repair), the same fed through an LDS ring by
+    loader waves, and the general LDS-exchange one."""
     monkeypatch.setenv("SOSRT_TRANSPORT", request.param)
     for s in list(I1_In._handles.values()):
         s.close()

@@ -19,7 +19,7 @@ s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["r
 d_tau = torch.from_numpy(w["tau"]).to(dev); d_P0a = torch.from_numpy(w["P0a"]).to(dev); d_P0r = torch.from_numpy(w["P0r"]).to(dev)
 d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev); d_n = torch.zeros(B, dtype=torch.int32, device=dev)
 st = torch.zeros((B, 2, 8), dtype=torch.int64, device=dev)
-for it in range(2):
+for it in range(int(os.environ.get("STAMP_ITERS", "2"))):
     check(lib().sosrt_debug_stamps(s._h, ctypes.c_void_p(st.data_ptr())))
     s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr())
     torch.cuda.synchronize()
