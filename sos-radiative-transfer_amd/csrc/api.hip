@@ -68,6 +68,7 @@ struct sosrt_handle {
     int* d_slabrows = nullptr;
     int* d_mainrows = nullptr;
     int nslab = 0, nmain = 0;
+    int max_main = 0, max_slab = 0;      // most plain / slab rows of any column
     // device: fields (internal)
     double *d_tau = nullptr, *d_P0a = nullptr, *d_P0r = nullptr;
     double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr, *d_E = nullptr;
@@ -76,6 +77,7 @@ struct sosrt_handle {
     int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr;
     int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel (+ repair)
     bool ring_ok = false;
+    int gemm_tail_cols = 128;            // at or below this many live columns the source function uses k_jn_gemm_tail (SOSRT_GEMM_TAIL)
     bool fast_ok = false;
     double* d_ratio = nullptr;
     int* h_poll = nullptr;               // pinned [2]
@@ -144,7 +146,7 @@ ColScalars scalars_of(sosrt_handle* h) {
 }
 
 // Jn for every row of the batch in one launch: plain rows against W_atm, slab rows against W_atm and W_aer
-void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active) {
+void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0) {
     GemmArgs ga;
     ga.A = In_1; ga.Wa = h->d_Wa; ga.Wr = h->d_Wr; ga.ca = h->d_rca; ga.cr = h->d_rcr;
     ga.rows_main = h->nslab > 0 ? h->d_mainrows : nullptr;
@@ -152,7 +154,13 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
     ga.rows_slab = h->d_slabrows; ga.n_slab = h->nslab;
     ga.D = h->g.D; ga.Dp = h->g.Dp; ga.Wld = h->g.Wld; ga.L = h->L; ga.C = Jn; ga.active = active;
     prof_begin(h, SOSRT_K_GEMM);
-    launch_gemm(h->stream, ga);
+    if (tail_cols > 0 && active) {
+        ga.B = h->B; ga.max_main = h->max_main; ga.max_slab = h->max_slab;
+        ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
+        launch_gemm_tail(h->stream, ga, tail_cols);
+    } else {
+        launch_gemm(h->stream, ga);
+    }
     prof_end(h, SOSRT_K_GEMM);
 }
 
@@ -179,6 +187,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
         h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : 1);
+    if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_LOADERS")) g_ring_loaders = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_DEBUG")) g_ring_debug = atoi(ev);   // timing experiments, see transport_ring.hip
@@ -376,6 +385,15 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
     HIPCHK(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
     h->nslab = (int)slab.size();
     h->nmain = (int)plain.size();
+    h->max_main = h->L; h->max_slab = 0;
+    if (geometry == SOSRT_GEOM_THREE_ZONE) {
+        h->max_main = 0;
+        for (int b = 0; b < B; ++b) {
+            const int ns = idx_down[b] - idx_up[b] + 1;
+            h->max_slab = ns > h->max_slab ? ns : h->max_slab;
+            h->max_main = h->L - ns > h->max_main ? h->L - ns : h->max_main;
+        }
+    }
     h->B = B; h->geom = geometry; h->surface = surface;
     h->have_cols = true;
     return 0;
@@ -519,14 +537,16 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     int n = 1;
     HIPCHK(hipMemcpyAsync(&h->h_poll[1], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(h->poll_ev[1], s));
+    int known_active = B;                    // live columns after the last order the host has seen (lags by one)
     while (n < h->max_orders) {
         if (n >= 2) {
             const int slot = (n - 1) & 1;
             HIPCHK(hipEventSynchronize(h->poll_ev[slot]));
             if (h->h_poll[slot] == 0) break;
+            known_active = h->h_poll[slot];
         }
         ++n;
-        run_source(h, In_1, h->d_Jn, h->d_active);
+        run_source(h, In_1, h->d_Jn, h->d_active, known_active <= h->gemm_tail_cols ? known_active : 0);
         if (g.nsmall > 0) {
             prof_begin(h, SOSRT_K_SMALLMU);
             launch_smallmu(s, g, B, d_tau, h->d_Jn, In, h->d_desc, h->d_active);

@@ -29,22 +29,36 @@ constexpr int B_LD = GEMM_BN + 16;
 
 // RT = MFMA row tiles per wave: 4 (64 rows) for the plain rows, 2 (32 rows) for the slab rows, whose
 // two passes over k would otherwise make their workgroups the critical path of the launch.
-template <int RT, bool SLAB>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile) {
+// local row of a tile list -> row of the batch (-1 beyond the end)
+struct ListRows {               // the host-built row lists over all columns (null list: identity)
+    const int* rows;
+    int n;
+    __device__ int operator()(int lr) const { return lr < n ? (rows ? rows[lr] : lr) : -1; }
+};
+struct ColumnRows {             // the plain or the slab rows of one column
+    int base, iu, ns, n;        // b*L, first slab row, slab rows, rows of this kind
+    bool slab;
+    __device__ int operator()(int lr) const {
+        if (lr >= n) return -1;
+        return base + (slab ? iu + lr : (lr < iu ? lr : lr + ns));
+    }
+};
+
+template <int RT, bool SLAB, bool DEEP = false, class RowOf = ListRows>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile, RowOf row_of,
+                                          bool check_active) {
     constexpr int BM = 16 * RT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int D = g.D, Dp = g.Dp, Wld = g.Wld;
     constexpr bool slab = SLAB;
-    const int* __restrict__ rows = slab ? g.rows_slab : g.rows_main;
-    const int nrows = slab ? g.n_slab : g.n_main;
     const int bm0 = tile * BM, bn0 = blockIdx.y * GEMM_BN;
 
     // the row this thread stages, its coefficients; skip the tile when every column it touches has converged
     const int arow = tid >> 2, akq = (tid & 3) * (GEMM_KC / 4);
     int grow = -1;
-    if (arow < BM && bm0 + arow < nrows) grow = rows ? rows[bm0 + arow] : bm0 + arow;
-    if (g.active) {
+    if (arow < BM) grow = row_of(bm0 + arow);
+    if (check_active && g.active) {
         if (tid == 0) *s_any = 0;
         __syncthreads();
         if ((tid & 3) == 0 && grow >= 0 && g.active[grow / g.L]) *s_any = 1;
@@ -123,15 +137,64 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
         }
     };
 
-    SOSRT_GLOAD_A(s0, 0);
-    SOSRT_GLOAD_B(0);
-    for (int c = 0; c < ntot; ++c) {
-        __syncthreads();                 // previous chunk consumed
-        SOSRT_LSTORE(s0, c);
-        __syncthreads();
-        SOSRT_GLOAD_A(s0, c + 1);
-        SOSRT_GLOAD_B(c + 1);
-        compute();
+    if (!DEEP) {
+        SOSRT_GLOAD_A(s0, 0);
+        SOSRT_GLOAD_B(0);
+        for (int c = 0; c < ntot; ++c) {
+            __syncthreads();                 // previous chunk consumed
+            SOSRT_LSTORE(s0, c);
+            __syncthreads();
+            SOSRT_GLOAD_A(s0, c + 1);
+            SOSRT_GLOAD_B(c + 1);
+            compute();
+        }
+    } else {
+        // Tail launches (few live columns: a workgroup is alone on its CU and nothing else hides the
+        // load latency): both operands staged two chunks ahead in two register sets, loop unrolled by
+        // two so that a set in flight is never copied.
+        struct Stage { double2 a[AQ]; double2 b[BQ]; };
+        Stage t0, t1;
+#define SOSRT_GLOAD2(ST, c_)                                                                              \
+    {                                                                                                     \
+        const int cc_ = min((c_), ntot - 1);                                                              \
+        const int pass_ = cc_ >= nck ? 1 : 0;                                                             \
+        const int kc_ = (cc_ - pass_ * nck) * GEMM_KC;                                                    \
+        _Pragma("unroll") for (int q = 0; q < AQ; ++q) {                                                  \
+            const int k0_ = kc_ + akq + 2 * q;                                                            \
+            ST.a[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + k0_)          \
+                                                 : make_double2(0, 0);                                    \
+        }                                                                                                 \
+        const double* __restrict__ W_ = pass_ ? g.Wr : g.Wa;                                              \
+        const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bn0 + bc;                                     \
+        _Pragma("unroll") for (int q = 0; q < BQ; ++q) ST.b[q] = *reinterpret_cast<const double2*>(Wp_ + 2 * q); \
+    }
+#define SOSRT_LSTORE2(ST, c_)                                                                             \
+    {                                                                                                     \
+        const double cf_ = (c_) >= nck ? coef_r : coef_a;                                                 \
+        _Pragma("unroll") for (int q = 0; q < AQ; ++q)                                                    \
+            *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                                 \
+                make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                           \
+        double2* sbp_ = reinterpret_cast<double2*>(&sB[bk * B_LD + bc]);                                  \
+        _Pragma("unroll") for (int q = 0; q < BQ; ++q) sbp_[q] = ST.b[q];                                 \
+    }
+        SOSRT_GLOAD2(t0, 0);
+        SOSRT_GLOAD2(t1, 1);
+        for (int c = 0; c < ntot; c += 2) {
+            __syncthreads();
+            SOSRT_LSTORE2(t0, c);
+            __syncthreads();
+            SOSRT_GLOAD2(t0, c + 2);
+            compute();
+            if (c + 1 < ntot) {
+                __syncthreads();
+                SOSRT_LSTORE2(t1, c + 1);
+                __syncthreads();
+                SOSRT_GLOAD2(t1, c + 3);
+                compute();
+            }
+        }
+#undef SOSRT_GLOAD2
+#undef SOSRT_LSTORE2
     }
 #undef SOSRT_GLOAD_A
 #undef SOSRT_GLOAD_B
@@ -141,9 +204,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     for (int i = 0; i < RT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int lr = bm0 + i * 16 + 4 * r + fk;
-            if (lr < nrows) {
-                const int gr = rows ? rows[lr] : lr;
+            const int gr = row_of(bm0 + i * 16 + 4 * r + fk);
+            if (gr >= 0) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = bn0 + wave * 32 + j * 16 + fr;
@@ -159,11 +221,67 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     __shared__ double sB[GEMM_KC * B_LD];
     __shared__ int s_any;
     const int tiles_main = (g.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT);
-    if ((int)blockIdx.x < tiles_main) gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, blockIdx.x);
-    else gemm_tile<2, true>(g, sA, sB, &s_any, (int)blockIdx.x - tiles_main);
+    if ((int)blockIdx.x < tiles_main) gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, blockIdx.x, ListRows{g.rows_main, g.n_main}, true);
+    else gemm_tile<2, true>(g, sA, sB, &s_any, (int)blockIdx.x - tiles_main, ListRows{g.rows_slab, g.n_slab}, true);
+}
+
+// The same contraction for launches with few live columns.  Tiling the row lists would launch a
+// workgroup for every tile of every column, and the few live tiles would queue behind thousands of
+// workgroups that only find out that their columns have converged.  Here blockIdx.x = (i, tile): the
+// workgroup finds the i-th live column itself (a prefix count over the live flags) and tiles that
+// column's rows: 16-row tiles for the slab rows, scheduled first because their double pass over k is
+// the critical path of the launch, then 32-row tiles for the plain rows.  Deeper staging, since such a
+// workgroup is alone on its CU.
+constexpr int TAIL_RT = 2, TAIL_RT_SLAB = 1;
+__global__ __launch_bounds__(256, 2) void k_jn_gemm_tail(GemmArgs g) {
+    __shared__ double sA[16 * TAIL_RT * A_LD];
+    __shared__ double sB[GEMM_KC * B_LD];
+    __shared__ int s_w[4];
+    __shared__ int s_col;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ts = (g.max_slab + 16 * TAIL_RT_SLAB - 1) / (16 * TAIL_RT_SLAB);
+    const int tm = (g.max_main + 16 * TAIL_RT - 1) / (16 * TAIL_RT);
+    const int ci = (int)blockIdx.x / (ts + tm), tt = (int)blockIdx.x % (ts + tm);
+    if (tid == 0) s_col = -1;
+    int before = 0;
+    for (int base = 0; base < g.B; base += 256) {
+        const bool f = base + tid < g.B && g.active[base + tid] != 0;
+        const unsigned long long mk = __ballot(f);
+        if (lane == 0) s_w[wave] = __popcll(mk);
+        __syncthreads();
+        int pre = before, tot = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) pre += s_w[w];
+            tot += s_w[w];
+        }
+        if (f && pre + __popcll(mk & ((2ull << lane) - 1)) == ci + 1) s_col = base + tid;
+        before += tot;
+        __syncthreads();
+        if (before > ci) break;
+    }
+    const int b = s_col;
+    if (b < 0) return;                                   // fewer live columns than the host's (lagging) count
+    const int iu = g.idx_up ? g.idx_up[b] : 0;
+    const int ns = g.idx_up ? g.idx_down[b] - iu + 1 : 0;
+    if (tt < ts) {
+        if (tt * 16 * TAIL_RT_SLAB >= ns) return;
+        gemm_tile<TAIL_RT_SLAB, true, true>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false);
+    } else {
+        const int t2 = tt - ts;
+        if (t2 * 16 * TAIL_RT >= g.L - ns) return;
+        gemm_tile<TAIL_RT, false, true>(g, sA, sB, nullptr, t2, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
+    }
 }
 
 }  // namespace
+
+void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols) {
+    const int ts = (a.max_slab + 16 * TAIL_RT_SLAB - 1) / (16 * TAIL_RT_SLAB);
+    const int tm = (a.max_main + 16 * TAIL_RT - 1) / (16 * TAIL_RT);
+    if (cols <= 0 || ts + tm <= 0) return;
+    dim3 grid(cols * (ts + tm), (a.D + GEMM_BN - 1) / GEMM_BN);
+    hipLaunchKernelGGL(k_jn_gemm_tail, grid, dim3(256), 0, s, a);
+}
 
 void launch_gemm(hipStream_t s, const GemmArgs& a) {
     const int tiles = (a.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT) + (a.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);

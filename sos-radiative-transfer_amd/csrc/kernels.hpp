@@ -126,8 +126,17 @@ struct GemmArgs {
     int D, Dp, Wld, L;
     double* C;
     const int* active;     // nullable: skip tiles whose columns have all converged
+    // k_jn_gemm_tail only: tiles are laid over the live columns (the i-th group of workgroups finds the
+    // i-th live column itself), not over the row lists
+    int B = 0;
+    const int* idx_up = nullptr;     // [B] first / last slab row of a column; null: no slab rows
+    const int* idx_down = nullptr;
+    int max_main = 0, max_slab = 0;  // most plain / slab rows any column has
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
+// few live columns (at most `cols`, an upper bound of the live count): smaller tiles, deeper staging,
+// workgroups only for live columns
+void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols);
 void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,

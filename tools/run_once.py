@@ -29,3 +29,5 @@ for _ in range(solves):
     s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr())
     torch.cuda.synchronize()
 print("orders", int((d_n.cpu().numpy() - 1).sum()), "max", int(d_n.max().item()))
+n = d_n.cpu().numpy()
+print("active columns per order (2..max):", [int((n >= k).sum()) for k in range(2, int(n.max()) + 1)])
