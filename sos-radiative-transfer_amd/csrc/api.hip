@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -77,11 +78,12 @@ struct sosrt_handle {
     int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr;
     int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel (+ repair)
     bool ring_ok = false;
-    int gemm_tail_cols = 128;            // at or below this many live columns the source function uses k_jn_gemm_tail (SOSRT_GEMM_TAIL)
+    int gemm_tail_cols = 1 << 30;        // at or below this many live columns (and below the batch) tiles are laid over live columns (SOSRT_GEMM_TAIL)
+    int gemm_small_cols = 100;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
     bool fast_ok = false;
     double* d_ratio = nullptr;
-    int* h_poll = nullptr;               // pinned [2]
-    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    int* h_pub = nullptr;                // pinned [2][2]: {live count, tag} published from the device
+    int pub_seq = 0;                     // tags are unique across solves
     int last_max_orders = 0;
     long long last_sum_orders = 0;
     Prof prof;
@@ -117,6 +119,25 @@ int need_gpu(sosrt_handle* h) {
     return 0;
 }
 
+// Live columns after the order whose tag is `tag`, as published by the source-function launch of the
+// next order (publish_live in kernels.hpp).  Spins on pinned memory; negative = error code.
+int wait_published(sosrt_handle* h, int tag) {
+    volatile int* slot = h->h_pub + 2 * (tag & 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 1;; ++it) {
+        if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) == tag) return slot[0];
+        if ((it & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(SOSRT_E_HIP, "order loop: %s", hipGetErrorString(q));
+            if (q == hipSuccess && __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != tag)
+                return fail(SOSRT_E_HIP, "order loop: the stream drained without publishing order tag %d", tag);
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return fail(SOSRT_E_HIP, "order loop: no progress for 120 s");
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 Conv make_conv(sosrt_handle* h, double tol) {
     Conv c;
     c.active = h->d_active; c.norders = h->d_norders; c.status = h->d_status;
@@ -146,18 +167,19 @@ ColScalars scalars_of(sosrt_handle* h) {
 }
 
 // Jn for every row of the batch in one launch: plain rows against W_atm, slab rows against W_atm and W_aer
-void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0) {
+void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0) {
     GemmArgs ga;
     ga.A = In_1; ga.Wa = h->d_Wa; ga.Wr = h->d_Wr; ga.ca = h->d_rca; ga.cr = h->d_rcr;
     ga.rows_main = h->nslab > 0 ? h->d_mainrows : nullptr;
     ga.n_main = h->nslab > 0 ? h->nmain : h->B * h->L;
     ga.rows_slab = h->d_slabrows; ga.n_slab = h->nslab;
     ga.D = h->g.D; ga.Dp = h->g.Dp; ga.Wld = h->g.Wld; ga.L = h->L; ga.C = Jn; ga.active = active;
+    if (pub_tag) { ga.nactive = h->d_nactive; ga.host_pub = h->h_pub; ga.tag = pub_tag; }
     prof_begin(h, SOSRT_K_GEMM);
     if (tail_cols > 0 && active) {
         ga.B = h->B; ga.max_main = h->max_main; ga.max_slab = h->max_slab;
         ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
-        launch_gemm_tail(h->stream, ga, tail_cols);
+        launch_gemm_tail(h->stream, ga, tail_cols, tail_cols <= h->gemm_small_cols);
     } else {
         launch_gemm(h->stream, ga);
     }
@@ -188,6 +210,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
         h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : 1);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
+    if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_LOADERS")) g_ring_loaders = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_DEBUG")) g_ring_debug = atoi(ev);   // timing experiments, see transport_ring.hip
@@ -231,9 +254,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_nactive, 1))) return e;
             if ((e = dalloc(&h->d_redo, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
-            HIPCHK(hipHostMalloc((void**)&h->h_poll, 2 * sizeof(int), hipHostMallocDefault));
-            HIPCHK(hipEventCreateWithFlags(&h->poll_ev[0], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->poll_ev[1], hipEventDisableTiming));
+            HIPCHK(hipHostMalloc((void**)&h->h_pub, 4 * sizeof(int), hipHostMallocCoherent));
+            memset(h->h_pub, 0, 4 * sizeof(int));
+
             HIPCHK(hipMemset(h->d_Wa, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
             HIPCHK(hipMemset(h->d_Wr, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
             HIPCHK(hipMemset(h->d_status, 0, mb * sizeof(int)));
@@ -260,9 +283,8 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_nactive, h->d_ratio, h->d_redo};
         for (void* p : ptrs)
             if (p) hipFree(p);
-        if (h->h_poll) hipHostFree(h->h_poll);
-        for (auto& e : h->poll_ev)
-            if (e) hipEventDestroy(e);
+        if (h->h_pub) hipHostFree(h->h_pub);
+
         for (auto& e : h->prof.ev) hipEventDestroy(e);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
@@ -530,23 +552,25 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     prof_end(h, SOSRT_K_FIRST);
 
     // Order loop (spec:309-458).  Converged columns are masked on the device (every kernel of an
-    // order returns at once for them).  r_k = number of live columns after order k is copied to a
-    // pinned slot after every order; before launching order k+1 the host checks r_{k-1}, which is
-    // already there while order k is still running, so the stream never drains inside the loop and
-    // at most one launch group runs on a fully converged batch.
+    // order returns at once for them).  r_k = number of live columns after order k is written to a
+    // pinned slot by the first workgroup of order k+1's source-function launch; before launching order
+    // k+1 the host checks r_{k-1}, which is there as soon as order k has started, so the stream never
+    // drains inside the loop and at most one launch group runs on a fully converged batch.
     int n = 1;
-    HIPCHK(hipMemcpyAsync(&h->h_poll[1], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(h->poll_ev[1], s));
     int known_active = B;                    // live columns after the last order the host has seen (lags by one)
+    const int tagbase = ((++h->pub_seq) & 0x3fff) << 16;      // tag of order n = tagbase + n
+    if (h->max_orders >= 65536) return fail(SOSRT_E_INVALID, "max_orders must be < 65536");
     while (n < h->max_orders) {
         if (n >= 2) {
-            const int slot = (n - 1) & 1;
-            HIPCHK(hipEventSynchronize(h->poll_ev[slot]));
-            if (h->h_poll[slot] == 0) break;
-            known_active = h->h_poll[slot];
+            const int live = wait_published(h, tagbase + n - 1);
+            if (live < 0) return live;
+            if (live == 0) break;
+            known_active = live;
         }
         ++n;
-        run_source(h, In_1, h->d_Jn, h->d_active, known_active <= h->gemm_tail_cols ? known_active : 0);
+        // this launch also publishes the live count after order n-1
+        run_source(h, In_1, h->d_Jn, h->d_active, (known_active < B && known_active <= h->gemm_tail_cols) ? known_active : 0,
+                   tagbase + n - 1);
         if (g.nsmall > 0) {
             prof_begin(h, SOSRT_K_SMALLMU);
             launch_smallmu(s, g, B, d_tau, h->d_Jn, In, h->d_desc, h->d_active);
@@ -563,8 +587,6 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                              h->use_etab ? h->d_E : nullptr, 0);
         }
         prof_end(h, SOSRT_K_TRANSPORT);
-        HIPCHK(hipMemcpyAsync(&h->h_poll[n & 1], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipEventRecord(h->poll_ev[n & 1], s));
         double* tmp = In_1; In_1 = In; In = tmp;
     }
     launch_finalize(s, B, cv, h->max_orders);

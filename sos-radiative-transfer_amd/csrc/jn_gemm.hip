@@ -114,9 +114,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
 #define SOSRT_LSTORE(ST, c_)                                                                              \
     {                                                                                                     \
         const double cf_ = (c_) >= nck ? coef_r : coef_a;                                                 \
+        if (arow < BM) {                       /* fewer rows than staging threads in the small tiles */      \
         _Pragma("unroll") for (int q = 0; q < AQ; ++q)                                                    \
             *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                                 \
                 make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                           \
+        }                                                                                                 \
         double2* sbp_ = reinterpret_cast<double2*>(&sB[bk * B_LD + bc]);                                  \
         sbp_[0] = sb0; sbp_[1] = sb1; sbp_[2] = sb2; sbp_[3] = sb3;                                       \
         if (BQ > 4) { sbp_[4] = sb4; sbp_[5] = sb5; sbp_[6] = sb6; sbp_[7] = sb7; }                       \
@@ -171,9 +173,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
 #define SOSRT_LSTORE2(ST, c_)                                                                             \
     {                                                                                                     \
         const double cf_ = (c_) >= nck ? coef_r : coef_a;                                                 \
+        if (arow < BM) {                       /* fewer rows than staging threads in the small tiles */      \
         _Pragma("unroll") for (int q = 0; q < AQ; ++q)                                                    \
             *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                                 \
                 make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                           \
+        }                                                                                                 \
         double2* sbp_ = reinterpret_cast<double2*>(&sB[bk * B_LD + bc]);                                  \
         _Pragma("unroll") for (int q = 0; q < BQ; ++q) sbp_[q] = ST.b[q];                                 \
     }
@@ -217,6 +221,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
 }
 
 __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
+    publish_live(g);
     __shared__ double sA[16 * (GEMM_RT > 2 ? GEMM_RT : 2) * A_LD];
     __shared__ double sB[GEMM_KC * B_LD];
     __shared__ int s_any;
@@ -225,22 +230,20 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     else gemm_tile<2, true>(g, sA, sB, &s_any, (int)blockIdx.x - tiles_main, ListRows{g.rows_slab, g.n_slab}, true);
 }
 
-// The same contraction for launches with few live columns.  Tiling the row lists would launch a
+// The same contraction once some columns have converged.  Tiling the row lists would launch a
 // workgroup for every tile of every column, and the few live tiles would queue behind thousands of
 // workgroups that only find out that their columns have converged.  Here blockIdx.x = (i, tile): the
 // workgroup finds the i-th live column itself (a prefix count over the live flags) and tiles that
 // column's rows: 16-row tiles for the slab rows, scheduled first because their double pass over k is
-// the critical path of the launch, then 32-row tiles for the plain rows.  Deeper staging, since such a
-// workgroup is alone on its CU.
-constexpr int TAIL_RT = 2, TAIL_RT_SLAB = 1;
-__global__ __launch_bounds__(256, 2) void k_jn_gemm_tail(GemmArgs g) {
-    __shared__ double sA[16 * TAIL_RT * A_LD];
-    __shared__ double sB[GEMM_KC * B_LD];
+// the critical path of the launch, then the tiles of the plain rows.
+constexpr int TAIL_RT_SLAB = 1;
+template <int RT, bool DEEP>
+__device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA, double* sB) {
     __shared__ int s_w[4];
     __shared__ int s_col;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ts = (g.max_slab + 16 * TAIL_RT_SLAB - 1) / (16 * TAIL_RT_SLAB);
-    const int tm = (g.max_main + 16 * TAIL_RT - 1) / (16 * TAIL_RT);
+    const int tm = (g.max_main + 16 * RT - 1) / (16 * RT);
     const int ci = (int)blockIdx.x / (ts + tm), tt = (int)blockIdx.x % (ts + tm);
     if (tid == 0) s_col = -1;
     int before = 0;
@@ -265,22 +268,41 @@ __global__ __launch_bounds__(256, 2) void k_jn_gemm_tail(GemmArgs g) {
     const int ns = g.idx_up ? g.idx_down[b] - iu + 1 : 0;
     if (tt < ts) {
         if (tt * 16 * TAIL_RT_SLAB >= ns) return;
-        gemm_tile<TAIL_RT_SLAB, true, true>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false);
+        gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false);
     } else {
         const int t2 = tt - ts;
-        if (t2 * 16 * TAIL_RT >= g.L - ns) return;
-        gemm_tile<TAIL_RT, false, true>(g, sA, sB, nullptr, t2, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
+        if (t2 * 16 * RT >= g.L - ns) return;
+        gemm_tile<RT, false, DEEP>(g, sA, sB, nullptr, t2, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
     }
+}
+
+// many live columns: the tile of the dense kernel
+__global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm_cols(GemmArgs g) {
+    publish_live(g);
+    __shared__ double sA[16 * GEMM_RT * A_LD];
+    __shared__ double sB[GEMM_KC * B_LD];
+    gemm_live_columns<GEMM_RT, false>(g, sA, sB);
+}
+// few live columns: 32-row tiles (more workgroups, so more CUs take part) and deeper staging, since
+// such a workgroup is alone on its CU
+constexpr int TAIL_RT = 2;
+__global__ __launch_bounds__(256, 2) void k_jn_gemm_tail(GemmArgs g) {
+    publish_live(g);
+    __shared__ double sA[16 * TAIL_RT * A_LD];
+    __shared__ double sB[GEMM_KC * B_LD];
+    gemm_live_columns<TAIL_RT, true>(g, sA, sB);
 }
 
 }  // namespace
 
-void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols) {
+void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles) {
+    const int rt = small_tiles ? TAIL_RT : GEMM_RT;
     const int ts = (a.max_slab + 16 * TAIL_RT_SLAB - 1) / (16 * TAIL_RT_SLAB);
-    const int tm = (a.max_main + 16 * TAIL_RT - 1) / (16 * TAIL_RT);
+    const int tm = (a.max_main + 16 * rt - 1) / (16 * rt);
     if (cols <= 0 || ts + tm <= 0) return;
     dim3 grid(cols * (ts + tm), (a.D + GEMM_BN - 1) / GEMM_BN);
-    hipLaunchKernelGGL(k_jn_gemm_tail, grid, dim3(256), 0, s, a);
+    if (small_tiles) hipLaunchKernelGGL(k_jn_gemm_tail, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_jn_gemm_cols, grid, dim3(256), 0, s, a);
 }
 
 void launch_gemm(hipStream_t s, const GemmArgs& a) {

@@ -132,11 +132,26 @@ struct GemmArgs {
     const int* idx_up = nullptr;     // [B] first / last slab row of a column; null: no slab rows
     const int* idx_down = nullptr;
     int max_main = 0, max_slab = 0;  // most plain / slab rows any column has
+    // The order loop's view of the batch: the first workgroup of the source-function launch of order
+    // n+1 (which starts when order n has finished) writes {live columns after order n, tag} to pinned
+    // host memory, where the host spins on the tag -- no copy, no event, no stream drain.
+    const int* nactive = nullptr;
+    int* host_pub = nullptr;         // pinned [2 slots][2]; slot = tag & 1
+    int tag = 0;
 };
+
+__device__ inline void publish_live(const GemmArgs& g) {
+    if (g.host_pub && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const int live = __hip_atomic_load(g.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int* slot = g.host_pub + 2 * (g.tag & 1);
+        __hip_atomic_store(slot, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(slot + 1, g.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 void launch_gemm(hipStream_t s, const GemmArgs& a);
-// few live columns (at most `cols`, an upper bound of the live count): smaller tiles, deeper staging,
-// workgroups only for live columns
-void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols);
+// some columns have converged (at most `cols` are live, an upper bound): workgroups only for live
+// columns; small_tiles: 32-row tiles and deeper staging for the last few
+void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles);
 void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
