@@ -75,7 +75,8 @@ struct sosrt_handle {
     double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr, *d_E = nullptr;
     int use_etab = 1;
     // convergence
-    int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr;
+    int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr, *d_erep = nullptr;
+    unsigned long long* d_tauhash = nullptr;
     int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel (+ repair)
     bool ring_ok = false;
     int gemm_tail_cols = 1 << 30;        // at or below this many live columns (and below the batch) tiles are laid over live columns (SOSRT_GEMM_TAIL)
@@ -253,6 +254,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_status, mb))) return e;
             if ((e = dalloc(&h->d_nactive, 1))) return e;
             if ((e = dalloc(&h->d_redo, mb))) return e;
+            if ((e = dalloc(&h->d_erep, mb))) return e;
+            if ((e = dalloc(&h->d_tauhash, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
             HIPCHK(hipHostMalloc((void**)&h->h_pub, 4 * sizeof(int), hipHostMallocCoherent));
             memset(h->h_pub, 0, 4 * sizeof(int));
@@ -280,7 +283,7 @@ int sosrt_destroy(sosrt_t* h) {
         void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
-                        h->d_nactive, h->d_ratio, h->d_redo};
+                        h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -475,7 +478,7 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     prof_end(h, SOSRT_K_SMALLMU);
     prof_begin(h, SOSRT_K_TRANSPORT);
     if (h->transport_mode >= 1 && h->fast_ok) {
-        launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E);
+        launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E, nullptr);
         HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E,
                          (h->transport_mode == 2 && h->ring_ok) ? 3 : 1);
@@ -540,7 +543,11 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
     const bool fast = h->transport_mode >= 1 && h->fast_ok;
     const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
-    if (h->use_etab || fast) launch_attenuation(s, g, B, d_tau, h->d_E);
+    if (h->use_etab || fast) {
+        // one attenuation table per distinct optical-depth profile
+        launch_tau_groups(s, g, B, d_tau, h->d_tauhash, h->d_erep);
+        launch_attenuation(s, g, B, d_tau, h->d_E, h->d_erep);
+    }
     if (fast) HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), s));
     double* In_1 = h->d_InA;
     double* In = h->d_InB;
@@ -579,12 +586,12 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         prof_begin(h, SOSRT_K_TRANSPORT);
         double* sv_n = d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr;
         if (fast) {
-            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, fast_mode);
+            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, fast_mode, h->d_erep);
             if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
-                launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 2);
+                launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 2, h->d_erep);
         } else {
             launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1,
-                             h->use_etab ? h->d_E : nullptr, 0);
+                             h->use_etab ? h->d_E : nullptr, 0, h->d_erep);
         }
         prof_end(h, SOSRT_K_TRANSPORT);
         double* tmp = In_1; In_1 = In; In = tmp;

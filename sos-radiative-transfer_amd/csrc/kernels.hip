@@ -409,7 +409,7 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     }
     const double* __restrict__ tau = a.tau + (size_t)b * L;
     const double* __restrict__ J = a.Jn + (size_t)b * L * D;
-    const double* __restrict__ Et = ETAB ? a.Etab + (size_t)b * L * D : nullptr;
+    const double* __restrict__ Et = ETAB ? a.Etab + (size_t)(a.erep ? a.erep[b] : b) * L * D : nullptr;
     double* __restrict__ In = a.In + (size_t)b * L * D;
     double* __restrict__ Iacc = ACC ? a.I + (size_t)b * L * D : nullptr;
     double* __restrict__ sv = SAVED ? a.saved + (size_t)b * a.saved_col_stride : nullptr;
@@ -723,11 +723,13 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
 
 // attenuation table of a column: E[t][m] = exp((tau_t - tau_{t-1}) / mu_m) for the downward lanes,
 // exp(-(tau_{t+1} - tau_t) / mu_m) for the upward ones; 0 for lanes that are not transported.
-__global__ void k_attenuation(Grid g, int B, const double* __restrict__ tau_all, double* __restrict__ E_all) {
+__global__ void k_attenuation(Grid g, int B, const double* __restrict__ tau_all, double* __restrict__ E_all,
+                              const int* __restrict__ erep) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t LD = (size_t)g.L * g.D;
     if (i >= (size_t)B * LD) return;
     const int b = (int)(i / LD), t = (int)((i % LD) / g.D), m = (int)(i % g.D);
+    if (erep && erep[b] != b) return;                        // shares the table of an earlier column
     const double* tau = tau_all + (size_t)b * g.L;
     const double mu = g.mu[m];
     double E = 0;
@@ -742,9 +744,52 @@ __global__ void k_attenuation(Grid g, int B, const double* __restrict__ tau_all,
     E_all[i] = E;
 }
 
-void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab) {
+void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep) {
     const size_t n = (size_t)B * g.L * g.D;
-    hipLaunchKernelGGL(k_attenuation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, B, tau, Etab);
+    hipLaunchKernelGGL(k_attenuation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, B, tau, Etab, erep);
+}
+
+// Columns of a parameter sweep usually share a few optical-depth profiles (the headline sweep: 8
+// profiles for 512 columns), and the attenuation table depends on nothing else.  Sharing one table
+// per profile keeps the tables in L2 / MALL instead of streaming one per column from HBM in every
+// order.  k_tau_hash: one 64-bit hash per column; k_tau_rep: the first earlier column with the same
+// hash and, checked value by value, the same profile.
+__global__ void k_tau_hash(int L, const double* __restrict__ tau_all, unsigned long long* __restrict__ hash) {
+    const int b = blockIdx.x, lane = threadIdx.x;            // one wave per column
+    const unsigned long long* t = reinterpret_cast<const unsigned long long*>(tau_all + (size_t)b * L);
+    unsigned long long h = 0;
+    for (int i = lane; i < L; i += 64) {
+        unsigned long long x = t[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+        h += x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    if (lane == 0) hash[b] = h;
+}
+__global__ void k_tau_rep(int L, const double* __restrict__ tau_all, const unsigned long long* __restrict__ hash,
+                          int* __restrict__ erep) {
+    const int b = blockIdx.x, lane = threadIdx.x;            // one wave per column
+    const unsigned long long hb = hash[b];
+    const double* tb = tau_all + (size_t)b * L;
+    int rep = b;
+    for (int c0 = 0; c0 < b && rep == b; c0 += 64) {
+        const int c = c0 + lane;
+        unsigned long long cand = __ballot(c < b && hash[c] == hb);
+        while (cand && rep == b) {
+            const int cc = c0 + __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const double* tc = tau_all + (size_t)cc * L;
+            bool same = true;
+            for (int i = lane; i < L; i += 64) same = same && (tb[i] == tc[i]);
+            if (__ballot(!same) == 0) rep = cc;
+        }
+    }
+    if (lane == 0) erep[b] = rep;
+}
+void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep) {
+    hipLaunchKernelGGL(k_tau_hash, dim3(B), dim3(64), 0, s, g.L, tau, hash);
+    hipLaunchKernelGGL(k_tau_rep, dim3(B), dim3(64), 0, s, g.L, tau, hash, erep);
 }
 
 template <int MAXT>
@@ -789,10 +834,10 @@ bool transport_fast_ok(const Plan& plan) {
 
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order,
-                      int accumulate, const double* Etab, int mode) {
+                      int accumulate, const double* Etab, int mode, const int* erep) {
     const int nt = round64(g.N);
     const size_t shm = (size_t)(g.L + 2 * TC * (nt + 2) + 2 * nt + nt / 64 + 2) * sizeof(double);
-    TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab, g_transport_stamps};
+    TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab, Etab ? erep : nullptr, g_transport_stamps};
     // the register budget follows the workgroup size: one column needs few waves, so they may be fat
     if (nt <= 128) launch_transport_t<128>(s, dim3(B), dim3(nt), shm, a, mode);
     else if (nt <= 256) launch_transport_t<256>(s, dim3(B), dim3(nt), shm, a, mode);

@@ -96,6 +96,7 @@ struct TransportArgs {
     int order;
     int accumulate;
     const double* Etab;
+    const int* erep;           // [B] column whose attenuation table this column uses (same tau profile); null: its own
     unsigned long long* stamps;   // diagnostic builds only: [B][8] cycle stamps of the sweeps (nullable)
 };
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
@@ -156,9 +157,12 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
-                      const double* Etab, int mode);
+                      const double* Etab, int mode, const int* erep = nullptr);
 bool transport_fast_ok(const Plan& plan);
-void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab);
+// erep (nullable): tables are built only for columns with erep[b] == b
+void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep);
+// erep[b] = first column with the same optical-depth profile as column b (hash[B] is scratch)
+void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep);
 void launch_fluxes(hipStream_t s, const Grid& g, int B, const double* tau, const double* I, const ColDesc* desc,
                    int beam_norm, double* fdn, double* fup);
 void launch_limit_rows(hipStream_t s, const Grid& g, int R, int table, const double* rows, double* out);

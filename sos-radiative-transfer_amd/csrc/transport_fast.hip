@@ -66,7 +66,7 @@ __global__ __launch_bounds__(MAXT) void k_transport_fast(TransportArgs a) {
     const double* __restrict__ tau = a.tau + (size_t)b * L;
     const int fbytes = L * D * 8, RB = D * 8;                  // bytes of a field of this column / of a row
     const __amdgpu_buffer_rsrc_t rJ = make_rsrc(a.Jn + (size_t)b * L * D, fbytes);
-    const __amdgpu_buffer_rsrc_t rE = make_rsrc(a.Etab + (size_t)b * L * D, fbytes);
+    const __amdgpu_buffer_rsrc_t rE = make_rsrc(a.Etab + (size_t)(a.erep ? a.erep[b] : b) * L * D, fbytes);
     const __amdgpu_buffer_rsrc_t rIn = make_rsrc(a.In + (size_t)b * L * D, fbytes);
     const __amdgpu_buffer_rsrc_t rI = make_rsrc(ACC ? a.I + (size_t)b * L * D : a.In, ACC ? fbytes : 0);
     const __amdgpu_buffer_rsrc_t rS = make_rsrc(SAVED ? a.saved + (size_t)b * a.saved_col_stride : a.In, SAVED ? fbytes : 0);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     // dbg (timing experiments only, results are wrong): 1 drops the loads, 2 the stores (zero-sized descriptors)
     const int lbytes = (dbg & 1) ? 0 : fbytes, sbytes = (dbg & 2) ? 0 : fbytes;
     const __amdgpu_buffer_rsrc_t rJ = make_rsrc(a.Jn + (size_t)b * L * D, lbytes);
-    const __amdgpu_buffer_rsrc_t rE = make_rsrc(a.Etab + (size_t)b * L * D, lbytes);
+    const __amdgpu_buffer_rsrc_t rE = make_rsrc(a.Etab + (size_t)(a.erep ? a.erep[b] : b) * L * D, lbytes);
     const __amdgpu_buffer_rsrc_t rIn = make_rsrc(a.In + (size_t)b * L * D, sbytes);
     const __amdgpu_buffer_rsrc_t rIl = make_rsrc(ACC ? a.I + (size_t)b * L * D : a.In, ACC ? lbytes : 0);
     const __amdgpu_buffer_rsrc_t rI = make_rsrc(ACC ? a.I + (size_t)b * L * D : a.In, ACC ? sbytes : 0);
