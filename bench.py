@@ -255,6 +255,17 @@ def main():
         r_tr = {"bound": "hbm", "kernel": "k_transport_ring", "achieved": tr_gbs, "peak": 8000.0, "unit": "GB/s",
                 "frac": tr_gbs / 8000.0, "traffic": None, "avg_launch_ms": tr_ms / max(tr_launches, 1),
                 "launches": tr_launches, "total_ms_per_step": tr_ms / a.steps}
+        # HBM bytes per launch from the committed PMC passes of the same workload (profiles/README.md): the
+        # counters cannot be read from inside this process
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if B == 512 and L == 200 and N == 128 and world == 1:
+                r_gemm["traffic"] = pmc["k_jn_gemm"]["hbm_bytes_per_launch"]
+                r_tr["traffic"] = pmc["k_transport_ring"]["hbm_bytes_per_launch"]
+                r_gemm["traffic_unit"] = r_tr["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
+        except (OSError, KeyError, ValueError):
+            pass
         # the roofline object is the kernel with the larger share of the timed region
         out["roofline"], out["roofline_other"] = (r_gemm, r_tr) if gemm_ms >= tr_ms else (r_tr, r_gemm)
         if pipe:

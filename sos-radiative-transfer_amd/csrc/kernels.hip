@@ -147,7 +147,11 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
                               const double* __restrict__ P0r_all, const ColDesc* __restrict__ desc,
                               double* __restrict__ I1_all, double* __restrict__ I_all, double* __restrict__ saved,
                               size_t saved_col_stride, Conv cv, int do_conv) {
+    // blockIdx.y = 0: the downward half of the field, 1: the upward half and the loop test.  The upward
+    // half needs the downward radiance at the surface (spec:211); it evaluates that one row itself (the
+    // same closed form, one row per zone) instead of waiting for the other workgroup.
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool up_half = blockIdx.y == 1;
     const int L = g.L, N = g.N, D = g.D;
     extern __shared__ double sm[];
     double* s_tau = sm;                 // [L]
@@ -197,7 +201,8 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             const double t_bd = z ? s_tau[d.r0[z] - 1] : 0.0;
             const double t_bs = z ? s_tau[d.r0[z]] : 0.0;
             const double e_bd = exp(-t_bd / mu0), e_bs = exp(-(T - t_bs) / mu0);
-            const int r0 = d.r0[z], r1 = d.r1[z];
+            const int r1 = d.r1[z];
+            const int r0 = up_half ? r1 : d.r0[z];          // the upward half only needs the last row of each zone
             for (int tb = r0; tb <= r1; tb += FU) {
                 double v[FU];
 #pragma unroll
@@ -215,7 +220,7 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
                 for (int u = 0; u < FU; ++u) {
                     const int t = tb + u;
                     if (t <= r1) {
-                        if (valid) {
+                        if (valid && !up_half) {
                             I1[(size_t)t * D + m] = v[u];
                             if (Iacc) Iacc[(size_t)t * D + m] = v[u];
                             if (sv) sv[(size_t)t * D + m] = v[u];
@@ -229,6 +234,7 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         s_sfc[tid] = vlast;                                   // I1[L-1][m]
         rdn = 1.0 / vlast;
     }
+    if (!up_half) return;
     __syncthreads();
     // ---- upward, m = N + tid, zones bottom to top ----
     {
@@ -302,7 +308,7 @@ void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, 
                         Conv cv, int do_conv) {
     const int nt = round64(g.N);
     const size_t shm = (size_t)(3 * g.L + nt + nt / 64 + 4) * sizeof(double);
-    hipLaunchKernelGGL(k_first_order, dim3(B), dim3(nt), shm, s, g, tau, P0a, P0r, desc, I1_out, I_out, saved,
+    hipLaunchKernelGGL(k_first_order, dim3(B, 2), dim3(nt), shm, s, g, tau, P0a, P0r, desc, I1_out, I_out, saved,
                        saved_col_stride, cv, do_conv);
 }
 

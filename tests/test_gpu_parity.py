@@ -266,3 +266,48 @@ def test_argument_errors_on_device():
     with pytest.raises(ValueError):
         s.first_order(np.zeros((1, 19)), np.zeros((1, 32)))            # wrong tau length
     s.close()
+
+
+def test_mixed_slab_geometries_and_shared_profiles_in_one_batch(transport_mode):
+    """Columns of one batch with different aerosol slabs (per-column idx_up / idx_down: the live-column
+    tiling of the source function maps plain and slab rows per column) and with repeated optical-depth
+    profiles (columns that share an attenuation table) -- each against its own oracle column."""
+    L, N = 40, 32
+    mu = inputs.direction_grid(N)
+    P0_r, P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)
+    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    #        mu0   z_up z_down  taer  rho
+    cols = [(0.50, 40, 12, 0.30, 0.15),
+            (0.80, 40, 12, 0.30, 0.40),     # same profile as column 0
+            (0.35, 60, 30, 0.30, 0.15),
+            (0.60, 25, 17, 0.80, 0.60),
+            (0.60, 25, 17, 0.05, 0.00),
+            (0.95, 90, 6, 1.50, 0.30),
+            (0.50, 40, 12, 0.30, 0.70),     # same profile as column 0
+            (0.25, 25, 17, 0.80, 0.90)]     # same profile as column 3
+    B = len(cols)
+    t_atm = 0.124
+    iu = np.empty(B, dtype=np.int32); idn = np.empty(B, dtype=np.int32)
+    tau = np.empty((B, L)); P0a = np.empty((B, 2 * N)); P0r = np.empty((B, 2 * N))
+    for b, (m0, zu, zd, ta, rho) in enumerate(cols):
+        iu[b], idn[b] = inputs.slab_indices(120, zu, zd, L)
+        tau[b] = inputs.tau_profile(t_atm, ta, 120, zu, zd, L)
+        P0a[b] = inputs.phase_function("rayleigh", N, mu, m0)[0]
+        P0r[b] = inputs.phase_function("hg", N, mu, m0, 0.7)[0]
+    assert len({(int(a), int(c)) for a, c in zip(iu, idn)}) >= 4
+    m0 = np.array([c[0] for c in cols]); ta = np.array([c[3] for c in cols]); rho = np.array([c[4] for c in cols])
+    s = Solver(L, N, max_batch=B, max_orders=200)
+    s.set_grid(mu); s.set_phase(P_atm, P_aer)
+    s.set_columns(iu, idn, m0, rho, 1.0, 0.95, t_atm / L, ta / (idn + 1 - iu), t_atm + ta, surface="specular")
+    r = s.solve(tau, P0a, P0r, tol=1e-4)
+    s.close()
+    for b, (mu0, zu, zd, taer, grd) in enumerate(cols):
+        col = O.make_column(mu0, 120, zu, zd, L, t_atm, taer, grd, 1.0, 0.95, N, P0a[b], P_atm, P0r[b], P_aer)
+        try:
+            ref = O.solve_column(col, literal=False)
+        except IndexError:
+            assert r.status[b] == _lib.COL_INDEXERROR, b
+            continue
+        assert r.status[b] == _lib.COL_OK, b
+        assert r.n[b] == ref.n, (b, r.n[b], ref.n)
+        assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
