@@ -84,6 +84,7 @@ struct sosrt_handle {
     bool fast_ok = false;
     double* d_ratio = nullptr;
     int* h_pub = nullptr;                // pinned [2][2]: {live count, tag} published from the device
+    bool need_small = true;              // some column keeps a k_smallmu value (known from the second order on)
     int pub_seq = 0;                     // tags are unique across solves
     int last_max_orders = 0;
     long long last_sum_orders = 0;
@@ -123,10 +124,13 @@ int need_gpu(sosrt_handle* h) {
 // Live columns after the order whose tag is `tag`, as published by the source-function launch of the
 // next order (publish_live in kernels.hpp).  Spins on pinned memory; negative = error code.
 int wait_published(sosrt_handle* h, int tag) {
-    volatile int* slot = h->h_pub + 2 * (tag & 1);
+    volatile int* slot = h->h_pub + 4 * (tag & 1);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 1;; ++it) {
-        if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) == tag) return slot[0];
+        if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) == tag) {
+            h->need_small = slot[2] != 0;
+            return slot[0];
+        }
         if ((it & 0x3fff) == 0) {
             const hipError_t q = hipStreamQuery(h->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(SOSRT_E_HIP, "order loop: %s", hipGetErrorString(q));
@@ -252,13 +256,13 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_active, mb))) return e;
             if ((e = dalloc(&h->d_norders, mb))) return e;
             if ((e = dalloc(&h->d_status, mb))) return e;
-            if ((e = dalloc(&h->d_nactive, 1))) return e;
+            if ((e = dalloc(&h->d_nactive, 2))) return e;          // live columns; any column needs k_smallmu
             if ((e = dalloc(&h->d_redo, mb))) return e;
             if ((e = dalloc(&h->d_erep, mb))) return e;
             if ((e = dalloc(&h->d_tauhash, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
-            HIPCHK(hipHostMalloc((void**)&h->h_pub, 4 * sizeof(int), hipHostMallocCoherent));
-            memset(h->h_pub, 0, 4 * sizeof(int));
+            HIPCHK(hipHostMalloc((void**)&h->h_pub, 8 * sizeof(int), hipHostMallocCoherent));
+            memset(h->h_pub, 0, 8 * sizeof(int));
 
             HIPCHK(hipMemset(h->d_Wa, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
             HIPCHK(hipMemset(h->d_Wr, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
@@ -539,8 +543,9 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     const size_t saved_stride = (size_t)h->max_orders * LD;
     Conv cv = make_conv(h, tol);
 
-    launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr);
-    HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
+    HIPCHK(hipMemsetAsync(h->d_nactive, 0, 2 * sizeof(int), s));
+    launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr, h->d_nactive + 1);
+    h->need_small = true;
     const bool fast = h->transport_mode >= 1 && h->fast_ok;
     const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) {
@@ -578,7 +583,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         // this launch also publishes the live count after order n-1
         run_source(h, In_1, h->d_Jn, h->d_active, (known_active < B && known_active <= h->gemm_tail_cols) ? known_active : 0,
                    tagbase + n - 1);
-        if (g.nsmall > 0) {
+        if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
             prof_begin(h, SOSRT_K_SMALLMU);
             launch_smallmu(s, g, B, d_tau, h->d_Jn, In, h->d_desc, h->d_active);
             prof_end(h, SOSRT_K_SMALLMU);

@@ -78,7 +78,7 @@ __device__ __forceinline__ int d_fix_bucket(double tau_ref) {
 // ------------------------------------------------------------------------------------------
 __global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, const double* __restrict__ tau,
                           ColDesc* __restrict__ desc, double* __restrict__ rowcoef_a,
-                          double* __restrict__ rowcoef_r) {
+                          double* __restrict__ rowcoef_r, int* __restrict__ need_small) {
     const int b = blockIdx.x;
     if (b >= B) return;
     __shared__ ColDesc d;
@@ -120,6 +120,8 @@ __global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, c
             const int k = d_fix_bucket(tref[z]);
             d.fixtab[z] = k;
             d.nfix[z] = (z < d.nz) ? g.fix[k].idx : 0;
+            // a |mu| < 0.01 lane below the rewritten ones keeps its k_smallmu value: the launch is needed
+            if (need_small && z < d.nz && g.nsmall > 0 && g.small_lanes[0] < g.N - d.nfix[z]) atomicOr(need_small, 1);
         }
         desc[b] = d;
     }
@@ -133,8 +135,9 @@ __global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, c
 }
 
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
-                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r) {
-    hipLaunchKernelGGL(k_prepare, dim3(B), dim3(128), 0, s, g, B, geom, surface, sc, tau, desc, rowcoef_a, rowcoef_r);
+                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small) {
+    hipLaunchKernelGGL(k_prepare, dim3(B), dim3(128), 0, s, g, B, geom, surface, sc, tau, desc, rowcoef_a, rowcoef_r,
+                       need_small);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -107,7 +107,7 @@ extern int g_ring_slots, g_ring_loaders, g_ring_debug;        // tuning (SOSRT_R
 extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
 
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
-                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r);
+                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small = nullptr);
 void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, const double* P0a, const double* P0r,
                         const ColDesc* desc, double* I1_out, double* I_out, double* saved, size_t saved_col_stride,
                         Conv cv, int do_conv);
@@ -136,16 +136,17 @@ struct GemmArgs {
     // The order loop's view of the batch: the first workgroup of the source-function launch of order
     // n+1 (which starts when order n has finished) writes {live columns after order n, tag} to pinned
     // host memory, where the host spins on the tag -- no copy, no event, no stream drain.
-    const int* nactive = nullptr;
-    int* host_pub = nullptr;         // pinned [2 slots][2]; slot = tag & 1
+    const int* nactive = nullptr;    // [2]: live columns, and whether any column needs k_smallmu (set by k_prepare)
+    int* host_pub = nullptr;         // pinned [2 slots][4] = {live, tag, needs k_smallmu, -}; slot = tag & 1
     int tag = 0;
 };
 
 __device__ inline void publish_live(const GemmArgs& g) {
     if (g.host_pub && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const int live = __hip_atomic_load(g.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int* slot = g.host_pub + 2 * (g.tag & 1);
+        int* slot = g.host_pub + 4 * (g.tag & 1);
         __hip_atomic_store(slot, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(slot + 2, g.nactive[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(slot + 1, g.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
