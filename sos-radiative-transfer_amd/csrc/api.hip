@@ -40,11 +40,16 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kProfPool = 8192;
 
+// HIP-event timing of launch groups.  An interval is a pair of events of the pool; when one bracket
+// closes and the next opens with nothing enqueued in between (the order loop: contraction, transport,
+// contraction, ...), the closing event is the next opening one, which halves the markers in the stream.
 struct Prof {
     bool on = false;
-    std::vector<hipEvent_t> ev;          // pairs
-    std::vector<int> kind;
-    size_t used = 0;
+    std::vector<hipEvent_t> ev;          // pool
+    std::vector<int> kind, first, last;  // per interval: kernel family, opening / closing event
+    size_t used = 0, nint = 0;           // events / intervals used
+    int open = -1;                       // opening event of the current bracket
+    int adjacent = -1;                   // closing event of the previous bracket, if nothing was enqueued since
 };
 }  // namespace
 
@@ -104,16 +109,27 @@ int dalloc(T** p, size_t n) {
 
 void prof_begin(sosrt_handle* h, int kind) {
     Prof& p = h->prof;
-    if (!p.on || p.used + 2 > p.ev.size()) return;
-    hipEventRecord(p.ev[p.used], h->stream);
+    p.open = -1;
+    if (!p.on || p.used + 2 > p.ev.size() || p.nint >= p.kind.size()) return;
+    if (p.adjacent >= 0) {
+        p.open = p.adjacent;
+    } else {
+        p.open = (int)p.used++;
+        hipEventRecord(p.ev[p.open], h->stream);
+    }
 }
 void prof_end(sosrt_handle* h, int kind) {
     Prof& p = h->prof;
-    if (!p.on || p.used + 2 > p.ev.size()) return;
-    hipEventRecord(p.ev[p.used + 1], h->stream);
-    p.kind[p.used / 2] = kind;
-    p.used += 2;
+    if (!p.on || p.open < 0) return;
+    const int e = (int)p.used++;
+    hipEventRecord(p.ev[e], h->stream);
+    p.kind[p.nint] = kind; p.first[p.nint] = p.open; p.last[p.nint] = e;
+    ++p.nint;
+    p.adjacent = e;
+    p.open = -1;
 }
+// work enqueued outside a bracket: the next bracket needs its own opening event
+void prof_break(sosrt_handle* h) { h->prof.adjacent = -1; }
 
 int need_gpu(sosrt_handle* h) {
     if (!h) return fail(SOSRT_E_INVALID, "null handle");
@@ -152,6 +168,7 @@ Conv make_conv(sosrt_handle* h, double tol) {
 
 int check_ready(sosrt_handle* h, int B, bool need_phase) {
     if (int e = need_gpu(h)) return e;
+    prof_break(h);
     if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
     if (need_phase && !h->have_phase) return fail(SOSRT_E_STATE, "sosrt_set_phase has not been called");
     if (!h->have_cols) return fail(SOSRT_E_STATE, "sosrt_set_columns has not been called");
@@ -543,6 +560,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     const size_t saved_stride = (size_t)h->max_orders * LD;
     Conv cv = make_conv(h, tol);
 
+    prof_break(h);
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, 2 * sizeof(int), s));
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr, h->d_nactive + 1);
     h->need_small = true;
@@ -825,7 +843,7 @@ int sosrt_profile_enable(sosrt_t* h, int on) {
     if (on && p.ev.empty()) {
         HIPCHK(hipSetDevice(h->device));
         p.ev.resize(2 * kProfPool);
-        p.kind.assign(kProfPool, -1);
+        p.kind.assign(kProfPool, -1); p.first.assign(kProfPool, 0); p.last.assign(kProfPool, 0);
         for (auto& e : p.ev) HIPCHK(hipEventCreate(&e));
     }
     p.on = on != 0;
@@ -835,7 +853,7 @@ int sosrt_profile_enable(sosrt_t* h, int on) {
 int sosrt_profile_reset(sosrt_t* h) {
     if (int e = need_gpu(h)) return e;
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->prof.used = 0;
+    h->prof.used = 0; h->prof.nint = 0; h->prof.adjacent = -1; h->prof.open = -1;
     return 0;
 }
 
@@ -845,10 +863,10 @@ int sosrt_profile_get(sosrt_t* h, int kernel, double* total_ms, long long* launc
     double tot = 0;
     long long cnt = 0;
     Prof& p = h->prof;
-    for (size_t i = 0; i + 1 < p.used; i += 2) {
-        if (p.kind[i / 2] != kernel) continue;
+    for (size_t i = 0; i < p.nint; ++i) {
+        if (p.kind[i] != kernel) continue;
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[p.first[i]], p.ev[p.last[i]]));
         tot += ms;
         ++cnt;
     }
