@@ -609,7 +609,11 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         prof_begin(h, SOSRT_K_TRANSPORT);
         double* sv_n = d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr;
         if (fast) {
-            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, fast_mode, h->d_erep);
+            // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
+            // need not stage those rows either
+            Grid gt = g;
+            if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
+            launch_transport(s, gt, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, fast_mode, h->d_erep);
             if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
                 launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 2, h->d_erep);
         } else {
