@@ -75,6 +75,13 @@ struct sosrt_handle {
     int* d_mainrows = nullptr;
     int nslab = 0, nmain = 0;
     int max_main = 0, max_slab = 0;      // most plain / slab rows of any column
+    // slab rows of the live-column tilings: one pass over ca W_atm + cr W_aer per distinct (ca, cr) of the batch
+    static constexpr int kMaxMixGroups = 32;
+    int mix_groups = 0;                  // 0: disabled (too many distinct pairs, or no slab)
+    bool mix_dirty = true;
+    double *d_Wmix = nullptr, *d_mixca = nullptr, *d_mixcr = nullptr;
+    int* d_mixgroup = nullptr;
+    size_t mix_capacity = 0;
     // device: fields (internal)
     double *d_tau = nullptr, *d_P0a = nullptr, *d_P0r = nullptr;
     double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr, *d_E = nullptr;
@@ -201,6 +208,7 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
     if (tail_cols > 0 && active) {
         ga.B = h->B; ga.max_main = h->max_main; ga.max_slab = h->max_slab;
         ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
+        if (h->mix_groups > 0 && !h->mix_dirty) { ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; }
         launch_gemm_tail(h->stream, ga, tail_cols, tail_cols <= h->gemm_small_cols);
     } else {
         launch_gemm(h->stream, ga);
@@ -276,6 +284,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_nactive, 2))) return e;          // live columns; any column needs k_smallmu
             if ((e = dalloc(&h->d_redo, mb))) return e;
             if ((e = dalloc(&h->d_erep, mb))) return e;
+            if ((e = dalloc(&h->d_mixgroup, mb))) return e;
+            if ((e = dalloc(&h->d_mixca, sosrt_handle::kMaxMixGroups))) return e;
+            if ((e = dalloc(&h->d_mixcr, sosrt_handle::kMaxMixGroups))) return e;
             if ((e = dalloc(&h->d_tauhash, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
             HIPCHK(hipHostMalloc((void**)&h->h_pub, 8 * sizeof(int), hipHostMallocCoherent));
@@ -304,7 +315,8 @@ int sosrt_destroy(sosrt_t* h) {
         void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
-                        h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash};
+                        h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
+                        h->d_mixgroup};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -371,6 +383,7 @@ int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer) {
     if (P_aer) h->plan.fold(P_aer, h->Wr_h);
     else h->Wr_h.clear();
     h->have_phase = true;
+    h->mix_dirty = true;
     if (h->gpu) {
         HIPCHK(hipSetDevice(h->device));
         const Grid& g = h->g;
@@ -438,6 +451,40 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
             const int ns = idx_down[b] - idx_up[b] + 1;
             h->max_slab = ns > h->max_slab ? ns : h->max_slab;
             h->max_main = h->L - ns > h->max_main ? h->L - ns : h->max_main;
+        }
+    }
+    h->mix_groups = 0;
+    h->mix_dirty = true;
+    if (geometry == SOSRT_GEOM_THREE_ZONE && h->nslab > 0) {
+        // distinct slab coefficient pairs (spec:321: (w_atm/4) f_atm on W_atm, (w_aer/4) f_aer on W_aer)
+        std::vector<double> gca, gcr;
+        std::vector<int> gid(B);
+        bool ok = true;
+        for (int b = 0; b < B && ok; ++b) {
+            const double da = dtau_atm[b], dr = dtau_aer[b];
+            const double ca = (alb_atm[b] / 4) * (da / (da + dr)), cr = (alb_aer[b] / 4) * (dr / (da + dr));
+            int k = 0;
+            while (k < (int)gca.size() && !(gca[k] == ca && gcr[k] == cr)) ++k;
+            if (k == (int)gca.size()) {
+                if (k == sosrt_handle::kMaxMixGroups) { ok = false; break; }
+                gca.push_back(ca); gcr.push_back(cr);
+            }
+            gid[b] = k;
+        }
+        if (ok) {
+            const size_t per = (size_t)h->g.Dp * h->g.Wld, need = per * gca.size();
+            if (need > h->mix_capacity) {
+                if (h->d_Wmix) hipFree(h->d_Wmix);
+                h->d_Wmix = nullptr; h->mix_capacity = 0;
+                if (hipMalloc((void**)&h->d_Wmix, need * sizeof(double)) == hipSuccess) h->mix_capacity = need;
+                else (void)hipGetLastError();
+            }
+            if (h->mix_capacity >= need) {
+                HIPCHK(hipMemcpy(h->d_mixca, gca.data(), gca.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_mixcr, gcr.data(), gcr.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_mixgroup, gid.data(), B * sizeof(int), hipMemcpyHostToDevice));
+                h->mix_groups = (int)gca.size();
+            }
         }
     }
     h->B = B; h->geom = geometry; h->surface = surface;
@@ -561,6 +608,10 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     Conv cv = make_conv(h, tol);
 
     prof_break(h);
+    if (h->mix_groups > 0 && h->mix_dirty) {
+        launch_wmix(s, (size_t)g.Dp * g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
+        h->mix_dirty = false;
+    }
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, 2 * sizeof(int), s));
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr, h->d_nactive + 1);
     h->need_small = true;

@@ -44,9 +44,11 @@ struct ColumnRows {             // the plain or the slab rows of one column
     }
 };
 
+// wmix (slab tiles of one column only): the column's combined matrix ca W_atm + cr W_aer -- one pass over k
+// with unit coefficients instead of two passes
 template <int RT, bool SLAB, bool DEEP = false, class RowOf = ListRows>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile, RowOf row_of,
-                                          bool check_active) {
+                                          bool check_active, const double* __restrict__ wmix = nullptr) {
     constexpr int BM = 16 * RT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
@@ -65,7 +67,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
         __syncthreads();
         if (!*s_any) return;
     }
-    const double coef_a = grow >= 0 ? g.ca[grow] : 0.0;
+    const double coef_a = grow >= 0 ? (wmix ? 1.0 : g.ca[grow]) : 0.0;
     const double coef_r = (slab && grow >= 0) ? g.cr[grow] : 0.0;
     const double* __restrict__ Arow = g.A + (size_t)(grow >= 0 ? grow : 0) * D;
 
@@ -103,7 +105,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
         const int cc_ = min((c_), ntot - 1);                                                              \
         const int pass_ = cc_ >= nck ? 1 : 0;                                                             \
         const int kc_ = (cc_ - pass_ * nck) * GEMM_KC;                                                    \
-        const double* __restrict__ W_ = pass_ ? g.Wr : g.Wa;                                              \
+        const double* __restrict__ W_ = wmix ? wmix : (pass_ ? g.Wr : g.Wa);                                              \
         const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bn0 + bc;                                     \
         sb0 = *reinterpret_cast<const double2*>(Wp_); sb1 = *reinterpret_cast<const double2*>(Wp_ + 2);    \
         sb2 = *reinterpret_cast<const double2*>(Wp_ + 4); sb3 = *reinterpret_cast<const double2*>(Wp_ + 6); \
@@ -166,7 +168,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
             ST.a[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + k0_)          \
                                                  : make_double2(0, 0);                                    \
         }                                                                                                 \
-        const double* __restrict__ W_ = pass_ ? g.Wr : g.Wa;                                              \
+        const double* __restrict__ W_ = wmix ? wmix : (pass_ ? g.Wr : g.Wa);                                              \
         const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bn0 + bc;                                     \
         _Pragma("unroll") for (int q = 0; q < BQ; ++q) ST.b[q] = *reinterpret_cast<const double2*>(Wp_ + 2 * q); \
     }
@@ -268,7 +270,11 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     const int ns = g.idx_up ? g.idx_down[b] - iu + 1 : 0;
     if (tt < ts) {
         if (tt * 16 * TAIL_RT_SLAB >= ns) return;
-        gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false);
+        if (g.Wmix)      // SLAB = false: a single pass, over the column's combined matrix
+            gemm_tile<TAIL_RT_SLAB, false, DEEP>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false,
+                                                 g.Wmix + (size_t)g.mix_group[b] * g.Dp * g.Wld);
+        else
+            gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false);
     } else {
         const int t2 = tt - ts;
         if (t2 * 16 * RT >= g.L - ns) return;
@@ -303,6 +309,19 @@ void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_til
     dim3 grid(cols * (ts + tm), (a.D + GEMM_BN - 1) / GEMM_BN);
     if (small_tiles) hipLaunchKernelGGL(k_jn_gemm_tail, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_jn_gemm_cols, grid, dim3(256), 0, s, a);
+}
+
+// Wmix[g] = ca[g] W_atm + cr[g] W_aer for every distinct slab coefficient pair of the batch
+__global__ void k_wmix(size_t n, int ngroups, const double* __restrict__ Wa, const double* __restrict__ Wr,
+                       const double* __restrict__ ca, const double* __restrict__ cr, double* __restrict__ Wmix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = Wa[i], r = Wr[i];
+    for (int gq = 0; gq < ngroups; ++gq) Wmix[(size_t)gq * n + i] = ca[gq] * a + cr[gq] * r;
+}
+void launch_wmix(hipStream_t s, size_t n, int ngroups, const double* Wa, const double* Wr, const double* ca, const double* cr,
+                 double* Wmix) {
+    hipLaunchKernelGGL(k_wmix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ngroups, Wa, Wr, ca, cr, Wmix);
 }
 
 void launch_gemm(hipStream_t s, const GemmArgs& a) {

@@ -133,6 +133,8 @@ struct GemmArgs {
     const int* idx_up = nullptr;     // [B] first / last slab row of a column; null: no slab rows
     const int* idx_down = nullptr;
     int max_main = 0, max_slab = 0;  // most plain / slab rows any column has
+    const double* Wmix = nullptr;    // [groups][Dp][Wld] ca W_atm + cr W_aer per distinct slab coefficient pair; null: two passes
+    const int* mix_group = nullptr;  // [B] group of a column
     // The order loop's view of the batch: the first workgroup of the source-function launch of order
     // n+1 (which starts when order n has finished) writes {live columns after order n, tag} to pinned
     // host memory, where the host spins on the tag -- no copy, no event, no stream drain.
@@ -151,6 +153,8 @@ __device__ inline void publish_live(const GemmArgs& g) {
     }
 }
 void launch_gemm(hipStream_t s, const GemmArgs& a);
+void launch_wmix(hipStream_t s, size_t n, int ngroups, const double* Wa, const double* Wr, const double* ca, const double* cr,
+                 double* Wmix);
 // some columns have converged (at most `cols` are live, an upper bound): workgroups only for live
 // columns; small_tiles: 32-row tiles and deeper staging for the last few
 void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles);
