@@ -116,3 +116,40 @@ def test_forcing_and_critical_albedo_drivers():
     assert bright < dark
     wc = forcing.critical_albedo(0.5, 0.124, [0.1, 0.3], 0.15, 1.0, **kw)
     assert wc.shape == (2,) and np.all((wc > 0) & (wc < 1))
+
+
+def test_large_ragged_batch_of_small_columns():
+    """600 columns (more than two 256-wide blocks of the live-column searches, ragged last block) that
+    converge at very different orders: batch invariance (reversed order gives the same bits) and a
+    sample against the oracle."""
+    import sos_oracle as O
+    from sosrt import inputs
+    from sosrt.main import SOS_Aer_batch
+    from util import RTOL, assert_close
+    L, N, B = 24, 64, 600
+    rng = np.random.default_rng(7)
+    mu0 = rng.uniform(0.15, 1.0, B)
+    taer = 10 ** rng.uniform(-2.5, 0.4, B)
+    rho = rng.uniform(0.0, 0.95, B)
+    mu = inputs.direction_grid(N)
+    P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
+    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    kw = dict(tauStar_atm=0.124, alb_aer=0.97, nb_layers=L, nb_angles=N, z_up=40, z_down=12, P_atm=P_atm, P_aer=P_aer,
+              max_orders=300, raise_on_error=False)
+    r = SOS_Aer_batch(mu0, taer, rho, **kw)
+    r2 = SOS_Aer_batch(mu0[::-1], taer[::-1], rho[::-1], **kw)
+    assert np.array_equal(r2.n[::-1], r.n) and np.array_equal(r2.status[::-1], r.status)
+    ok = r.status == 0
+    assert ok.sum() > 0.5 * B and r.n[ok].max() > 3 * r.n[ok].min()
+    assert np.array_equal(r2.I[::-1][ok], r.I[ok])
+    for b in (0, 255, 256, 511, 512, 599):
+        P0a = inputs.phase_function("rayleigh", N, mu, mu0[b])[0]
+        P0r = inputs.phase_function("hg", N, mu, mu0[b], 0.7)[0]
+        col = O.make_column(mu0[b], 120, 40, 12, L, 0.124, taer[b], rho[b], 1.0, 0.97, N, P0a, P_atm, P0r, P_aer)
+        try:
+            ref = O.solve_column(col, literal=False)
+        except IndexError:
+            assert r.status[b] == 1, b
+            continue
+        assert r.status[b] == 0 and r.n[b] == ref.n, (b, r.status[b], r.n[b], ref.n)
+        assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
