@@ -899,7 +899,8 @@ int sosrt_profile_enable(sosrt_t* h, int on) {
         HIPCHK(hipSetDevice(h->device));
         p.ev.resize(2 * kProfPool);
         p.kind.assign(kProfPool, -1); p.first.assign(kProfPool, 0); p.last.assign(kProfPool, 0);
-        for (auto& e : p.ev) HIPCHK(hipEventCreate(&e));
+        // timing markers only: no system-scope fence (cache write-back / invalidate) at each of them
+        for (auto& e : p.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     }
     p.on = on != 0;
     return 0;
