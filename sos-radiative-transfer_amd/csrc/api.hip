@@ -92,7 +92,7 @@ struct sosrt_handle {
     int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel (+ repair)
     bool ring_ok = false;
     int gemm_tail_cols = 1 << 30;        // at or below this many live columns (and below the batch) tiles are laid over live columns (SOSRT_GEMM_TAIL)
-    int gemm_small_cols = 100;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
+    int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
     bool fast_ok = false;
     double* d_ratio = nullptr;
     int* h_pub = nullptr;                // pinned [2][2]: {live count, tag} published from the device
