@@ -114,10 +114,25 @@ int dalloc(T** p, size_t n) {
     return 0;
 }
 
+// the pools grow on demand (a long profiled run must not end up with timings of its first steps only)
+bool prof_room(Prof& p) {
+    if (p.used + 2 > p.ev.size()) {
+        const size_t n0 = p.ev.size();
+        p.ev.resize(n0 + 4096);
+        for (size_t i = n0; i < p.ev.size(); ++i)
+            if (hipEventCreateWithFlags(&p.ev[i], hipEventDisableSystemFence) != hipSuccess) { p.ev.resize(i); break; }
+        if (p.used + 2 > p.ev.size()) return false;
+    }
+    if (p.nint >= p.kind.size()) {
+        const size_t n = p.kind.size() + 4096;
+        p.kind.resize(n, -1); p.first.resize(n, 0); p.last.resize(n, 0);
+    }
+    return true;
+}
 void prof_begin(sosrt_handle* h, int kind) {
     Prof& p = h->prof;
     p.open = -1;
-    if (!p.on || p.used + 2 > p.ev.size() || p.nint >= p.kind.size()) return;
+    if (!p.on || !prof_room(p)) return;
     if (p.adjacent >= 0) {
         p.open = p.adjacent;
     } else {
