@@ -84,3 +84,15 @@ def test_inputs():
     for i in range(int(d["n"])):
         ta, tr, z0, zu, zd, L = d["p%d" % i]
         assert np.array_equal(O.tau_profile(ta, tr, z0, zu, zd, int(L)), d["tau%d" % i])
+
+
+def test_fp32_contraction_misses_the_parity_bar():
+    """The tolerance study behind the choice of an FP64 contraction (tests/study_mixed_precision.py):
+    float operands put the converged field 1e-9..1e-8 away, a float accumulator 1e-7; a hi + lo
+    operand split only helps if the products are accumulated in double, which no FP32 matrix
+    instruction does."""
+    import io
+    import study_mixed_precision as S
+    res = S.study(L=40, N=32, ncol=2, out=io.StringIO())
+    assert res["fp32/fp64"]["err"] > 1e-9 and res["fp32"]["err"] > 1e-8
+    assert res["2xfp32"]["err"] < 1e-12 and res["2xfp32/f32"]["err"] > 1e-9
