@@ -47,14 +47,14 @@ struct ColumnRows {             // the plain or the slab rows of one column
 // wmix (slab tiles of one column only): the column's combined matrix ca W_atm + cr W_aer -- one pass over k
 // with unit coefficients instead of two passes
 template <int RT, bool SLAB, bool DEEP = false, class RowOf = ListRows>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile, RowOf row_of,
-                                          bool check_active, const double* __restrict__ wmix = nullptr) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile, int bn0,
+                                          RowOf row_of, bool check_active, const double* __restrict__ wmix = nullptr) {
     constexpr int BM = 16 * RT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int D = g.D, Dp = g.Dp, Wld = g.Wld;
     constexpr bool slab = SLAB;
-    const int bm0 = tile * BM, bn0 = blockIdx.y * GEMM_BN;
+    const int bm0 = tile * BM;
 
     // the row this thread stages, its coefficients; skip the tile when every column it touches has converged
     const int arow = tid >> 2, akq = (tid & 3) * (GEMM_KC / 4);
@@ -227,9 +227,17 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     __shared__ double sA[16 * (GEMM_RT > 2 ? GEMM_RT : 2) * A_LD];
     __shared__ double sB[GEMM_KC * B_LD];
     __shared__ int s_any;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  The column tiles of one row
+    // tile read the same rows of In_1: numbering them 8 apart puts them on one XCD, a few dispatches apart,
+    // so that In_1 comes from HBM once instead of once per column tile.
     const int tiles_main = (g.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT);
-    if ((int)blockIdx.x < tiles_main) gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, blockIdx.x, ListRows{g.rows_main, g.n_main}, true);
-    else gemm_tile<2, true>(g, sA, sB, &s_any, (int)blockIdx.x - tiles_main, ListRows{g.rows_slab, g.n_slab}, true);
+    const int tiles = tiles_main + (g.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);
+    const int nct = (g.D + GEMM_BN - 1) / GEMM_BN;
+    const int id = blockIdx.x;
+    const int tile = (id / (8 * nct)) * 8 + (id & 7), bn0 = ((id >> 3) % nct) * GEMM_BN;
+    if (tile >= tiles) return;
+    if (tile < tiles_main) gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, tile, bn0, ListRows{g.rows_main, g.n_main}, true);
+    else gemm_tile<2, true>(g, sA, sB, &s_any, tile - tiles_main, bn0, ListRows{g.rows_slab, g.n_slab}, true);
 }
 
 // The same contraction once some columns have converged.  Tiling the row lists would launch a
@@ -271,14 +279,14 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     if (tt < ts) {
         if (tt * 16 * TAIL_RT_SLAB >= ns) return;
         if (g.Wmix)      // SLAB = false: a single pass, over the column's combined matrix
-            gemm_tile<TAIL_RT_SLAB, false, DEEP>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false,
-                                                 g.Wmix + (size_t)g.mix_group[b] * g.Dp * g.Wld);
+            gemm_tile<TAIL_RT_SLAB, false, DEEP>(g, sA, sB, nullptr, tt, blockIdx.y * GEMM_BN, ColumnRows{b * g.L, iu, ns, ns, true},
+                                                 false, g.Wmix + (size_t)g.mix_group[b] * g.Dp * g.Wld);
         else
-            gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, ColumnRows{b * g.L, iu, ns, ns, true}, false);
+            gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, blockIdx.y * GEMM_BN, ColumnRows{b * g.L, iu, ns, ns, true}, false);
     } else {
         const int t2 = tt - ts;
         if (t2 * 16 * RT >= g.L - ns) return;
-        gemm_tile<RT, false, DEEP>(g, sA, sB, nullptr, t2, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
+        gemm_tile<RT, false, DEEP>(g, sA, sB, nullptr, t2, blockIdx.y * GEMM_BN, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
     }
 }
 
@@ -327,7 +335,8 @@ void launch_wmix(hipStream_t s, size_t n, int ngroups, const double* Wa, const d
 void launch_gemm(hipStream_t s, const GemmArgs& a) {
     const int tiles = (a.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT) + (a.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);
     if (tiles <= 0) return;
-    dim3 grid(tiles, (a.D + GEMM_BN - 1) / GEMM_BN);
+    const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nct));
     hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), 0, s, a);
 }
 
