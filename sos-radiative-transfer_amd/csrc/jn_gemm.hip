@@ -254,7 +254,11 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ts = (g.max_slab + 16 * TAIL_RT_SLAB - 1) / (16 * TAIL_RT_SLAB);
     const int tm = (g.max_main + 16 * RT - 1) / (16 * RT);
-    const int ci = (int)blockIdx.x / (ts + tm), tt = (int)blockIdx.x % (ts + tm);
+    // same XCD-aware numbering as the dense kernel: the column tiles of a row tile 8 apart
+    const int nct = (g.D + GEMM_BN - 1) / GEMM_BN;
+    const int id = blockIdx.x;
+    const int xq = (id / (8 * nct)) * 8 + (id & 7), bn0 = ((id >> 3) % nct) * GEMM_BN;
+    const int ci = xq / (ts + tm), tt = xq % (ts + tm);
     if (tid == 0) s_col = -1;
     int before = 0;
     for (int base = 0; base < g.B; base += 256) {
@@ -279,14 +283,14 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     if (tt < ts) {
         if (tt * 16 * TAIL_RT_SLAB >= ns) return;
         if (g.Wmix)      // SLAB = false: a single pass, over the column's combined matrix
-            gemm_tile<TAIL_RT_SLAB, false, DEEP>(g, sA, sB, nullptr, tt, blockIdx.y * GEMM_BN, ColumnRows{b * g.L, iu, ns, ns, true},
+            gemm_tile<TAIL_RT_SLAB, false, DEEP>(g, sA, sB, nullptr, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true},
                                                  false, g.Wmix + (size_t)g.mix_group[b] * g.Dp * g.Wld);
         else
-            gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, blockIdx.y * GEMM_BN, ColumnRows{b * g.L, iu, ns, ns, true}, false);
+            gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true}, false);
     } else {
         const int t2 = tt - ts;
         if (t2 * 16 * RT >= g.L - ns) return;
-        gemm_tile<RT, false, DEEP>(g, sA, sB, nullptr, t2, blockIdx.y * GEMM_BN, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
+        gemm_tile<RT, false, DEEP>(g, sA, sB, nullptr, t2, bn0, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
     }
 }
 
@@ -314,7 +318,8 @@ void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_til
     const int ts = (a.max_slab + 16 * TAIL_RT_SLAB - 1) / (16 * TAIL_RT_SLAB);
     const int tm = (a.max_main + 16 * rt - 1) / (16 * rt);
     if (cols <= 0 || ts + tm <= 0) return;
-    dim3 grid(cols * (ts + tm), (a.D + GEMM_BN - 1) / GEMM_BN);
+    const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid((unsigned)((cols * (ts + tm) + 7) / 8 * 8 * nct));
     if (small_tiles) hipLaunchKernelGGL(k_jn_gemm_tail, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_jn_gemm_cols, grid, dim3(256), 0, s, a);
 }
