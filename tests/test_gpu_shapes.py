@@ -153,3 +153,53 @@ def test_large_ragged_batch_of_small_columns():
             continue
         assert r.status[b] == 0 and r.n[b] == ref.n, (b, r.status[b], r.n[b], ref.n)
         assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
+
+
+def test_c5_full_size_batch_on_device():
+    """BASELINE's largest configuration at full size -- 4096 columns, L = 400, N = 256 (33 GB of fields on
+    the device) -- through the device-pointer entry point: every column converges, the run is
+    deterministic, order counts are monotone along the sweep axes, and one sampled column matches the
+    oracle."""
+    import os
+    import sys
+    import torch
+    import sos_oracle as O
+    from sosrt import inputs
+    from sosrt.solver import Solver
+    from util import RTOL, assert_close
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    L, N = 400, 256
+    w = bench.build_sweep(4096, L, N, 0, 1)
+    B = w["B"]
+    assert B == 4096
+    dev = torch.device("cuda", 0)
+    s = Solver(L, N, max_batch=B, max_orders=128)
+    s.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    s.set_grid(w["mu"]); s.set_phase(w["P_atm"], w["P_aer"])
+    s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
+                  w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
+    d_tau = torch.from_numpy(w["tau"]).to(dev)
+    d_P0a = torch.from_numpy(w["P0a"]).to(dev); d_P0r = torch.from_numpy(w["P0r"]).to(dev)
+    d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    digests = []
+    for _ in range(2):
+        d_I.zero_()
+        s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr(),
+                       d_status=d_st.data_ptr())
+        torch.cuda.synchronize()
+        digests.append((d_I[:, 0, N:].clone(), d_I[:, L - 1, :N].clone(), d_n.clone()))
+    assert int(d_st.abs().sum().item()) == 0
+    assert all(torch.equal(a, b) for a, b in zip(*digests))                 # bit-reproducible
+    n = d_n.cpu().numpy().reshape(16, 16, 16)                                # axes: mu0, tau*_aer, grd_alb
+    assert n.min() >= 2 and (np.diff(n, axis=1) >= 0).all() and (np.diff(n, axis=2) >= 0).all()
+    assert torch.isfinite(d_I[::97]).all() and float(d_I[:, 0, N + 1:].min()) > 0
+    b = 16 * 16 * 5 + 16 * 9 + 4
+    mu = w["mu"]
+    col = O.make_column(w["mu0"][b], 120, 25, 17, L, w["tau_atm"], w["taer"][b], w["rho"][b], 1.0, w["alb_aer"], N,
+                        w["P0a"][b], w["P_atm"], w["P0r"][b], w["P_aer"])
+    ref = O.solve_column(col, literal=False)
+    assert int(d_n[b].item()) == ref.n
+    assert_close(d_I[b].cpu().numpy(), ref.I, RTOL, "column %d" % b)
+    s.close()
