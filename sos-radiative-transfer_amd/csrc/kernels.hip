@@ -734,28 +734,30 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
 // exp(-(tau_{t+1} - tau_t) / mu_m) for the upward ones; 0 for lanes that are not transported.
 __global__ void k_attenuation(Grid g, int B, const double* __restrict__ tau_all, double* __restrict__ E_all,
                               const int* __restrict__ erep) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t LD = (size_t)g.L * g.D;
-    if (i >= (size_t)B * LD) return;
-    const int b = (int)(i / LD), t = (int)((i % LD) / g.D), m = (int)(i % g.D);
-    if (erep && erep[b] != b) return;                        // shares the table of an earlier column
+    const int b = blockIdx.y;                                 // grid (slices, columns): whole workgroups of the
+    if (erep && erep[b] != b) return;                        // columns that share an earlier column's table leave at once
+    const int LD = g.L * g.D;
     const double* tau = tau_all + (size_t)b * g.L;
-    const double mu = g.mu[m];
-    double E = 0;
-    if (m < g.N) {
-        const bool stdl = m <= g.N - 2 && !(fabs(mu) < kMuThreshold);
-        const double dl = tau[t] - tau[max(t - 1, 0)];
-        if (stdl) E = exp(dl * (1.0 / mu));
-    } else {
-        const double dl = tau[min(t + 1, g.L - 1)] - tau[t];
-        if (m > g.N) E = exp(-dl * (1.0 / mu));
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < LD; i += gridDim.x * blockDim.x) {
+        const int t = i / g.D, m = i % g.D;
+        const double mu = g.mu[m];
+        double E = 0;
+        if (m < g.N) {
+            const bool stdl = m <= g.N - 2 && !(fabs(mu) < kMuThreshold);
+            const double dl = tau[t] - tau[max(t - 1, 0)];
+            if (stdl) E = exp(dl * (1.0 / mu));
+        } else {
+            const double dl = tau[min(t + 1, g.L - 1)] - tau[t];
+            if (m > g.N) E = exp(-dl * (1.0 / mu));
+        }
+        E_all[(size_t)b * LD + i] = E;
     }
-    E_all[i] = E;
 }
 
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep) {
-    const size_t n = (size_t)B * g.L * g.D;
-    hipLaunchKernelGGL(k_attenuation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, B, tau, Etab, erep);
+    // with shared tables few columns have work: more slices per column then
+    const int slices = erep ? 64 : 8;
+    hipLaunchKernelGGL(k_attenuation, dim3(slices, B), dim3(256), 0, s, g, B, tau, Etab, erep);
 }
 
 // Columns of a parameter sweep usually share a few optical-depth profiles (the headline sweep: 8
