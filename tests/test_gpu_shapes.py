@@ -203,3 +203,44 @@ def test_c5_full_size_batch_on_device():
     assert int(d_n[b].item()) == ref.n
     assert_close(d_I[b].cpu().numpy(), ref.I, RTOL, "column %d" % b)
     s.close()
+
+
+def test_many_distinct_slab_coefficients_fall_back_to_two_passes():
+    """More distinct (ca, cr) slab coefficient pairs than the combined-matrix cache holds (32): the
+    live-column slab tiles then take the two-pass path.  Same answers as with few pairs."""
+    import sos_oracle as O
+    from sosrt import inputs
+    from sosrt.main import SOS_Aer_batch
+    from util import RTOL, assert_close
+    L, N, B = 40, 64, 48
+    mu = inputs.direction_grid(N)
+    P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
+    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    mu0 = np.full(B, 0.6)
+    taer = np.geomspace(0.02, 1.5, B)            # 48 distinct optical depths -> 48 distinct (f_atm, f_aer)
+    rho = np.linspace(0.05, 0.7, B)
+    walb = np.linspace(0.85, 1.0, B)
+    kw = dict(tauStar_atm=0.124, alb_aer=walb, nb_layers=L, nb_angles=N, z_up=40, z_down=12, P_atm=P_atm, P_aer=P_aer,
+              max_orders=200, raise_on_error=False)
+    r = SOS_Aer_batch(mu0, taer, rho, **kw)
+    P0a = inputs.phase_function("rayleigh", N, mu, 0.6)[0]
+    P0r = inputs.phase_function("hg", N, mu, 0.6, 0.7)[0]
+    checked = 0
+    for b in (0, 17, 33, 47):
+        col = O.make_column(0.6, 120, 40, 12, L, 0.124, taer[b], rho[b], 1.0, walb[b], N, P0a, P_atm, P0r, P_aer)
+        try:
+            ref = O.solve_column(col, literal=False)
+        except IndexError:
+            assert r.status[b] == 1, b
+            continue
+        assert r.status[b] == 0 and r.n[b] == ref.n, (b, r.status[b], r.n[b], ref.n)
+        assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
+        checked += 1
+    assert checked >= 2
+    # the same columns in groups of 8 (few pairs per batch: the combined-matrix path) agree to rounding
+    for g0 in (0, 40):
+        sl = slice(g0, g0 + 8)
+        rs = SOS_Aer_batch(mu0[sl], taer[sl], rho[sl], **dict(kw, alb_aer=walb[sl]))
+        ok = (r.status[sl] == 0) & (rs.status == 0)
+        assert np.array_equal(rs.n[ok], r.n[sl][ok])
+        assert_close(rs.I[ok], r.I[sl][ok], 1e-12, "two-pass vs combined-matrix slab tiles")
