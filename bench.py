@@ -5,9 +5,18 @@ One step = one pass of the hot path (I1 -> [Jn -> In] x orders, convergence test
 one batch of synthetic columns whose inputs are already resident in HBM.  The workload is the
 BASELINE C4 sweep shape: 512 columns = 8 mu0 x 8 tau*_aer x 8 grd_alb, L=200, N=128, Rayleigh
 atmosphere + HG(g=0.7) aerosol stand-in (the EVA log-normal Mie phase function needs miepython,
-unavailable offline), specular surface, fp64.  With N GPUs every rank solves its own 512-column
-sweep (weak scaling; rank r uses a different aerosol single-scattering albedo) and the TOA /
-surface radiances and order counts are gathered to rank 0 over RCCL once per step.
+unavailable offline), specular surface, fp64.  P0(mu, mu0) of every column is built on the device
+(sosrt_phase_p0_dev) before the timed region.
+
+Several GPUs (`--gpus N`): one process per GPU.  When no launcher environment is present (no WORLD_SIZE)
+the N rank processes are started from here through torch.distributed.run, before anything touches a GPU.
+  --scaling weak (default): every rank solves its own 512-column sweep (rank r uses a different aerosol
+      single-scattering albedo); the TOA / surface radiances and order counts are gathered to rank 0 once
+      per step.
+  --scaling strong: ONE sweep (BASELINE configs[3]: 512 columns over the node, 64 per GPU at N = 8) dealt to
+      the ranks by expected work (sosrt.dist.shard_indices) and the whole fields gathered to rank 0 once per
+      step (sosrt.dist.gather_columns) -- RCCL over xGMI.
+No collective runs inside the order loop.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
@@ -23,9 +32,21 @@ sys.path.insert(0, os.path.join(ROOT, "sos-radiative-transfer_amd"))
 import numpy as np
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix, vendor datasheet; the microarch guide lists no f64 row
+PMC_FILE = "r02_pmc_traffic.json"
 
 
-def build_sweep(n_columns, L, N, rank, world):
+def kernel_sources_sha():
+    """Digest of the kernel sources the PMC traffic figures belong to."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("jn_gemm.hip", "transport_ring.hip", "kernels.hpp", "transport_util.hpp"):
+        with open(os.path.join(ROOT, "sos-radiative-transfer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_sweep(n_columns, L, N, rank, world, vary_albedo=True):
+    """Host-side description of one sweep (the per-column P0 rows are built on the device by the caller)."""
     from sosrt import inputs
     side = max(1, round(n_columns ** (1 / 3)))
     mu0 = np.linspace(0.2, 1.0, side)
@@ -36,41 +57,101 @@ def build_sweep(n_columns, L, N, rank, world):
     mu = inputs.direction_grid(N)
     iu, idn = inputs.slab_indices(120, 25, 17, L)
     tau_atm = 0.124
-    alb_aer = float(np.linspace(0.97, 0.90, world)[rank]) if world > 1 else 0.97
+    alb_aer = float(np.linspace(0.97, 0.90, world)[rank]) if (world > 1 and vary_albedo) else 0.97
     tau = np.stack([inputs.tau_profile(tau_atm, t, 120, 25, 17, L) for t in TA])
     P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
     P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
-    cache = {}
-    for m in np.unique(M0):
-        cache[float(m)] = (inputs.phase_function("rayleigh", N, mu, m)[0], inputs.phase_function("hg", N, mu, m, 0.7)[0])
-    P0a = np.stack([cache[float(m)][0] for m in M0])
-    P0r = np.stack([cache[float(m)][1] for m in M0])
-    return dict(B=B, L=L, N=N, mu=mu, tau=tau, P_atm=P_atm, P_aer=P_aer, P0a=P0a, P0r=P0r, mu0=M0, taer=TA, rho=RH,
+    return dict(B=B, L=L, N=N, mu=mu, tau=tau, P_atm=P_atm, P_aer=P_aer, mu0=M0, taer=TA, rho=RH,
                 idx_up=iu, idx_down=idn, tau_atm=tau_atm, alb_aer=alb_aer)
 
 
-def cpu_baseline(w, seconds_budget=25.0):
-    """The oracle in its literal (reference-cost) mode on one host core, on a bounded sample of the
-    same sweep: columns are taken evenly across the sweep until the budget is used."""
+def host_p0(w):
+    """(P0_atm, P0_aer) rows [B, 2N] on the host (tools and tests; bench itself builds them on the device)."""
+    from sosrt import inputs
+    cache = {}
+    for m in np.unique(w["mu0"]):
+        cache[float(m)] = (inputs.phase_function("rayleigh", w["N"], w["mu"], m)[0], inputs.phase_function("hg", w["N"], w["mu"], m, 0.7)[0])
+    return np.stack([cache[float(m)][0] for m in w["mu0"]]), np.stack([cache[float(m)][1] for m in w["mu0"]])
+
+
+def take(w, idx):
+    """The sub-sweep of the columns `idx` (strong scaling: this rank's shard)."""
+    out = dict(w)
+    for k in ("tau", "mu0", "taer", "rho"):
+        out[k] = np.ascontiguousarray(w[k][idx])
+    out["B"] = len(idx)
+    return out
+
+
+def oracle_column(O, w, b, P0a, P0r):
+    return O.Column(tau=w["tau"][b], mu=w["mu"], N=w["N"], idx_up=w["idx_up"], idx_down=w["idx_down"], mu0=float(w["mu0"][b]),
+                    grd_alb=float(w["rho"][b]), alb_atm=1.0, alb_aer=w["alb_aer"], dtau_atm=w["tau_atm"] / w["L"],
+                    dtau_aer=float(w["taer"][b]) / (w["idx_down"] + 1 - w["idx_up"]),
+                    tauStar_tot=w["tau_atm"] + float(w["taer"][b]), P0_atm=P0a, P_atm=w["P_atm"], P0_aer=P0r, P_aer=w["P_aer"])
+
+
+def _baseline_one(args):
+    """One column of the sweep through the oracle in literal (reference-cost) mode; runs in a worker process."""
+    w, b = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sos_oracle as O
+    P0a = O.phase_rayleigh(w["N"], w["mu"], float(w["mu0"][b]))[0]
+    P0r = O.phase_hg(w["N"], w["mu"], float(w["mu0"][b]), 0.7)[0]
+    t0 = time.perf_counter()
+    s = O.solve_column(oracle_column(O, w, b, P0a, P0r), literal=True)
+    return s.n - 1, time.perf_counter() - t0
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def cpu_baseline(w, seconds_budget=20.0):
+    """The oracle in its literal (reference-cost) mode on the host cores of this box, on a bounded sample of the same
+    sweep.  `value`: ONE core (the reference is single-threaded), columns taken evenly across the sweep until the
+    budget is used.  `all_cores`: one process per usable core over independent columns (how a user of the reference
+    would fill the box), one column per process."""
     B = w["B"]
+    model, logical, usable = cpu_info()
     order = np.linspace(0, B - 1, min(B, 8)).astype(int)
     done, orders, t0 = 0, 0, time.perf_counter()
     for b in order:
-        col = O.Column(tau=w["tau"][b], mu=w["mu"], N=w["N"], idx_up=w["idx_up"], idx_down=w["idx_down"], mu0=float(w["mu0"][b]),
-                       grd_alb=float(w["rho"][b]), alb_atm=1.0, alb_aer=w["alb_aer"], dtau_atm=w["tau_atm"] / w["L"],
-                       dtau_aer=float(w["taer"][b]) / (w["idx_down"] + 1 - w["idx_up"]),
-                       tauStar_tot=w["tau_atm"] + float(w["taer"][b]), P0_atm=w["P0a"][b], P_atm=w["P_atm"],
-                       P0_aer=w["P0r"][b], P_aer=w["P_aer"])
-        s = O.solve_column(col, literal=True)
+        k, _ = _baseline_one((w, int(b)))
         done += 1
-        orders += s.n - 1
+        orders += k
         if time.perf_counter() - t0 > seconds_budget:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "columns/s", "cores": 1, "kind": "port",
-            "sample": "%d columns of the same sweep (evenly spaced), %d orders, oracle literal mode, %.1f s" % (done, orders, dt)}
+    out = {"value": done / dt, "unit": "columns/s", "cores": 1, "kind": "port",
+           "sample": "%d columns of the same sweep (evenly spaced), %d orders, oracle literal mode, %.1f s" % (done, orders, dt),
+           "cpu_model": model, "host_cores_logical": logical, "host_cores_usable": usable}
+    procs = max(1, min(usable, B, 64))
+    if procs > 1:
+        import multiprocessing as mp
+        cols = np.linspace(0, B - 1, procs).astype(int)
+        wl = {k: w[k] for k in ("tau", "mu", "N", "L", "idx_up", "idx_down", "mu0", "rho", "alb_aer", "tau_atm", "taer", "P_atm", "P_aer")}
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        t1 = time.perf_counter()
+        with mp.get_context("spawn").Pool(procs) as pool:
+            res = pool.map(_baseline_one, [(wl, int(b)) for b in cols], chunksize=1)
+        dtp = time.perf_counter() - t1
+        out["all_cores"] = {"value": procs / dtp, "unit": "columns/s", "cores": procs,
+                            "sample": "%d columns, one process each, %d orders, %.1f s wall (slowest column %.1f s)" % (
+                                procs, sum(r[0] for r in res), dtp, max(r[1] for r in res))}
+    return out
 
 
 def main():
@@ -87,7 +168,25 @@ def main():
     ap.add_argument("--pipelined", type=int, default=3,
                     help="after the timed region, also measure the throughput with this many steps in flight on "
                          "separate streams (0: skip); reported beside the headline value, never instead of it")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--gather", choices=("digest", "field"), default=None,
+                    help="what rank 0 receives per step: TOA/surface rows + order counts, or the whole fields "
+                         "(default: digest for weak scaling, field for strong)")
+    ap.add_argument("--check-columns", type=int, default=3, help="columns compared with the oracle after the timed region")
     a = ap.parse_args()
+    if a.gather is None:
+        a.gather = "field" if a.scaling == "strong" else "digest"
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, before this process touches a GPU
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     import torch
     import torch.distributed as dist
@@ -114,12 +213,25 @@ def main():
     from sosrt import _lib
     from sosrt.solver import Solver
 
-    w = build_sweep(a.columns, a.layers, a.angles, rank, world)
+    from sosrt import dist as sdist
+    strong = a.scaling == "strong" and world > 1
+    w_all = build_sweep(a.columns, a.layers, a.angles, rank, world, vary_albedo=not strong)
+    n_global = w_all["B"]
+    if strong:
+        # ONE sweep over the node: columns dealt by expected work, every rank gets about the same sum of orders
+        mine = sdist.shard_indices(n_global, world, rank, sdist.expected_orders(w_all["tau_atm"] + w_all["taer"], w_all["rho"]))
+        w = take(w_all, mine)
+    else:
+        mine = np.arange(n_global)
+        w = w_all
     B, L, N = w["B"], w["L"], w["N"]
     D = 2 * N
+    if B == 0:
+        raise SystemExit("rank %d has no columns: --columns must be at least --gpus" % rank)
     d_tau = torch.from_numpy(w["tau"]).to(dev)
-    d_P0a = torch.from_numpy(w["P0a"]).to(dev)
-    d_P0r = torch.from_numpy(w["P0r"]).to(dev)
+    d_mu0 = torch.from_numpy(np.ascontiguousarray(w["mu0"])).to(dev)
+    d_P0a = torch.empty((B, D), dtype=torch.float64, device=dev)
+    d_P0r = torch.empty((B, D), dtype=torch.float64, device=dev)
 
     # `inflight` independent solves may be in flight at once, each on its own handle and HIP stream:
     # the order loop of a sweep ends in a long tail of launches over its few slowest-converging
@@ -139,11 +251,11 @@ def main():
             self.done = torch.cuda.Event()
 
         def solve(self):
-            """Enqueue one step on this lane's stream; returns (digest tensor or None, completion event)."""
+            """Enqueue one step on this lane's stream; returns (what rank 0 is to receive or None, completion event)."""
             self.s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), self.I.data_ptr(), tol=1e-4,
                                 d_n_orders=self.n.data_ptr(), d_status=self.st.data_ptr())
             dig = None
-            if world > 1:
+            if world > 1 and a.gather == "digest":
                 with torch.cuda.stream(self.stream):
                     dig = torch.cat([self.I[:, 0, N:], self.I[:, L - 1, :N], self.n.to(torch.float64)[:, None]], dim=1).contiguous()
             ev = torch.cuda.Event()
@@ -153,28 +265,44 @@ def main():
     torch.cuda.synchronize(dev)
     lanes = [Lane() for _ in range(max(1, a.inflight))]
     main_stream = torch.cuda.current_stream(dev)
+    # the inputs of the path that depend on mu0: one P0 row per column, built where the solve reads them
+    # (phase:86-103,148-165 on the device; outside the timed region, like the other inputs)
+    lanes[0].s.phase_p0_device("rayleigh", d_mu0.data_ptr(), d_P0a.data_ptr(), B)
+    lanes[0].s.phase_p0_device("hg", d_mu0.data_ptr(), d_P0r.data_ptr(), B, g=0.7)
+    lanes[0].s.synchronize()
 
     from concurrent.futures import ThreadPoolExecutor
     execs = [ThreadPoolExecutor(max_workers=1) for _ in lanes]       # a lane runs its steps in order
+    gathered = {}
 
     def lane_step(i):
         torch.cuda.set_device(local_rank)
         return lanes[i].solve()
 
     def run_steps(k):
-        """k steps dealt round-robin to the lanes.  With several ranks the per-column digests (TOA-up row,
-        surface-down row, order count) of every step are gathered to rank 0 -- the only collective --
-        from this thread, in step order, behind the step's completion event."""
-        futs = [execs[step % len(lanes)].submit(lane_step, step % len(lanes)) for step in range(k)]
-        for f in futs:
+        """k steps dealt round-robin to the lanes.  With several ranks the results of every step are gathered to
+        rank 0 -- the only collective -- from this thread, in step order, behind the step's completion event:
+        per-column digests (TOA-up row, surface-down row, order count) or the whole fields."""
+        futs = [(step % len(lanes), execs[step % len(lanes)].submit(lane_step, step % len(lanes))) for step in range(k)]
+        for li, f in futs:
             dig, ev = f.result()
             if world > 1:
                 main_stream.wait_event(ev)
-                if backend != "nccl":                 # gloo gathers host tensors
-                    ev.synchronize()
-                    dig = dig.cpu()
-                bufs = [torch.empty_like(dig) for _ in range(world)] if rank == 0 else None
-                dist.gather(dig, bufs, dst=0)
+                if a.gather == "field":
+                    ln = lanes[li]
+                    loc = {"I": ln.I, "n": ln.n}
+                    if backend != "nccl":             # gloo gathers host tensors
+                        ev.synchronize()
+                        loc = {k2: v.cpu() for k2, v in loc.items()}
+                    res = sdist.gather_columns(loc, mine if strong else np.arange(B), n_global if strong else B, dst=0)
+                    if rank == 0:
+                        gathered.clear(); gathered.update(res)
+                else:
+                    if backend != "nccl":
+                        ev.synchronize()
+                        dig = dig.cpu()
+                    bufs = [torch.empty_like(dig) for _ in range(world)] if rank == 0 else None
+                    dist.gather(dig, bufs, dst=0)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -202,6 +330,36 @@ def main():
         fo_ms += ln.s.profile_get(_lib.K_FIRST)[0]
         ln.s.profile_enable(False)
 
+    # Outside the timed region: sampled columns of the field the last timed step left on the device against the
+    # oracle (vectorised mode, same arithmetic as the reference to rounding).  Rank 0, its own columns.
+    check = None
+    if rank == 0 and a.check_columns > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import sos_oracle as O
+        I_host = lanes[(a.steps - 1) % len(lanes)].I
+        P0a_h, P0r_h = d_P0a.cpu().numpy(), d_P0r.cpu().numpy()
+        cols = sorted(set(np.linspace(0, B - 1, min(B, a.check_columns)).astype(int).tolist()))
+        worst, same_n, p0_err = 0.0, True, 0.0
+        for b in cols:
+            P0a = O.phase_rayleigh(N, w["mu"], float(w["mu0"][b]))[0]
+            P0r = O.phase_hg(N, w["mu"], float(w["mu0"][b]), 0.7)[0]
+            p0_err = max(p0_err, float(np.max(np.abs(P0a_h[b] - P0a) / P0a)), float(np.max(np.abs(P0r_h[b] - P0r) / P0r)))
+            ref = O.solve_column(oracle_column(O, w, b, P0a, P0r), literal=False)
+            got = I_host[b].cpu().numpy()
+            scale = np.max(np.abs(ref.I))
+            sig = np.abs(ref.I) > 1e-9 * scale
+            err = max(float(np.max(np.abs(got - ref.I)[sig] / np.abs(ref.I)[sig])), float(np.max(np.abs(got - ref.I)) / scale))
+            worst = max(worst, err)
+            same_n = same_n and int(n_host[b]) == ref.n
+        check = {"columns": [int(mine[b]) for b in cols], "max_rel_err_vs_oracle": worst, "orders_match": bool(same_n),
+                 "p0_max_rel_err_vs_oracle": p0_err, "tolerance": 1e-10, "ok": bool(worst <= 1e-10 and same_n)}
+        if world > 1 and a.gather == "field" and gathered:
+            # the gathered field holds every rank's columns in global order: rank 0's own must be where they belong
+            gI = gathered["I"]
+            sel = torch.as_tensor(np.asarray(mine if strong else np.arange(B))[cols], device=gI.device)
+            mineI = torch.stack([I_host[b] for b in cols]).to(gI.device)
+            check["gather_places_columns"] = bool(torch.equal(gI[sel], mineI))
+
     # Beside the headline (one step at a time, one stream: every kernel timing above is of a launch that
     # has the GPU to itself): the same steps with `--pipelined` of them in flight on separate streams and
     # handles.  The tail of one sweep's order loop then overlaps the dense launches of the next.
@@ -220,14 +378,21 @@ def main():
         pipe = {"steps_in_flight": a.pipelined, "steps": psteps, "value": B * psteps / dtp, "unit": "columns/s",
                 "ms_per_step": dtp / psteps * 1e3}
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    cpu_t = dev if backend == "nccl" else "cpu"
+    t = torch.tensor([dt], dtype=torch.float64, device=cpu_t)
+    per_rank = torch.zeros(world, 2, dtype=torch.float64, device=cpu_t)
+    per_rank[rank, 0] = B
+    per_rank[rank, 1] = orders_per_step
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(per_rank)
     dt = float(t.item())
+    per_rank = per_rank.cpu().numpy()
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        value = world * B * a.steps / dt
+        total_columns = int(per_rank[:, 0].sum())
+        value = total_columns * a.steps / dt
         # dominant kernel: the Jn contraction.  Algorithmic flops per launch group = 2 L D^2 per live
         # (column, order) pair (no credit for the second slab matrix or for padding).
         flops = 2.0 * L * D * D * orders_per_step * a.steps
@@ -236,17 +401,25 @@ def main():
         out = {
             "metric": "SOS columns/sec to 1e-4 convergence (Ntau=200, Nmu=128)",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4 sweep: %d columns/GPU = mu0 x tau*_aer x grd_alb grid, L=%d, N=%d (D=%d), "
-                                   "Rayleigh atm + HG(0.7) aerosol stand-in, specular surface, tol 1e-4" % (B, L, N, D),
-                       "columns_per_gpu": B, "orders_per_step": orders_per_step, "max_order": int(n_host.max()),
+            "config": {"workload": "C4 sweep: %s = mu0 x tau*_aer x grd_alb grid, L=%d, N=%d (D=%d), "
+                                   "Rayleigh atm + HG(0.7) aerosol stand-in, specular surface, tol 1e-4" % (
+                                       ("%d columns over %d GPUs" % (n_global, world)) if strong else ("%d columns/GPU" % B), L, N, D),
+                       "columns_per_gpu": [int(x) for x in per_rank[:, 0]] if world > 1 else B,
+                       "orders_per_step": orders_per_step, "orders_per_step_per_rank": [int(x) for x in per_rank[:, 1]],
+                       "max_order": int(n_host.max()),
                        "not_converged": int((st_host != 0).sum()), "inflight_solves": max(1, a.inflight),
-                       "parallelism": "columns sharded x%d, gather only" % world},
+                       "p0": "built on the device (sosrt_phase_p0_dev), outside the timed region",
+                       "gather": (a.gather + " to rank 0 once per step") if world > 1 else "none",
+                       "parallelism": ("one sweep dealt to %d ranks by expected orders, gather only" % world) if strong else
+                                      ("columns sharded x%d, gather only" % world)},
             "roofline": None, "roofline_other": None,
             "kernel_ms_per_step": {"k_jn_gemm": gemm_ms / a.steps, "k_transport": tr_ms / a.steps,
                                    "k_first_order": fo_ms / a.steps},
         }
+        if check is not None:
+            out["check"] = check
         r_gemm = {"bound": "mfma", "kernel": "k_jn_gemm", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                   "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                   "avg_launch_ms": gemm_ms / max(gemm_launches, 1), "launches": gemm_launches,
@@ -255,15 +428,16 @@ def main():
         r_tr = {"bound": "hbm", "kernel": "k_transport_ring", "achieved": tr_gbs, "peak": 8000.0, "unit": "GB/s",
                 "frac": tr_gbs / 8000.0, "traffic": None, "avg_launch_ms": tr_ms / max(tr_launches, 1),
                 "launches": tr_launches, "total_ms_per_step": tr_ms / a.steps}
-        # HBM bytes per launch from the committed PMC passes of the same workload (profiles/README.md): the
-        # counters cannot be read from inside this process
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of the same workload (the counters cannot be
+        # read from inside this process).  The committed file names the source revision of the kernels it was
+        # measured on; it is used only while those sources are unchanged, otherwise traffic stays null.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 pmc = json.load(f)
-            if B == 512 and L == 200 and N == 128 and world == 1:
+            if B == 512 and L == 200 and N == 128 and world == 1 and pmc.get("kernel_sources_sha") == kernel_sources_sha():
                 r_gemm["traffic"] = pmc["k_jn_gemm"]["hbm_bytes_per_launch"]
                 r_tr["traffic"] = pmc["k_transport_ring"]["hbm_bytes_per_launch"]
-                r_gemm["traffic_unit"] = r_tr["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
+                r_gemm["traffic_unit"] = r_tr["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/%s)" % PMC_FILE
         except (OSError, KeyError, ValueError):
             pass
         # the roofline object is the kernel with the larger share of the timed region

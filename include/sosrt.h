@@ -63,6 +63,10 @@ int sosrt_destroy(sosrt_t* h);
 /* run on a caller-provided hipStream_t (e.g. the current torch stream); NULL = the handle's own */
 int sosrt_set_stream(sosrt_t* h, void* hip_stream);
 int sosrt_synchronize(sosrt_t* h);
+/* I_saved_out of the solves that follow holds `slots` orders per column ([B][slots][L][2N], 1 <= slots <=
+ * max_orders; orders beyond are computed but not stored).  Default: max_orders.  The reference's list
+ * I_saved (spec:304-305,458) has exactly n entries: solve once without it to learn n, then once with slots = max n. */
+int sosrt_set_saved_orders(sosrt_t* h, int slots);
 
 /* ---- per-sweep setup ------------------------------------------------------------------------ */
 /* direction grid mu[2N] (spec:59-61).  Builds the trapezoid weights of np.trapz(.., mu) used by
@@ -98,9 +102,11 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
 
 /* ---- column level: the order loop of spec:301-458 ------------------------------------------- */
 /* Iterates I1 -> [Jn -> In] until max(In/I at TOA-up, In/I at surface-down) < tol (spec:309) per
- * column.  Outputs: I_out [B][L][2N]; I_saved_out [B][max_orders][L][2N] or NULL (spec:304-305,458);
+ * column.  Outputs: I_out [B][L][2N]; I_saved_out [B][slots][L][2N] or NULL (spec:304-305,458; slots =
+ * max_orders unless sosrt_set_saved_orders was called);
  * n_orders_out [B] (the final n of spec:307-310); status_out [B] or NULL; I1_in (nullable,
- * [B][L][2N]) replaces the computed first order (used to pin the Lambertian n>=2 path). */
+ * [B][L][2N]) replaces the computed first order (used to pin the Lambertian n>=2 path).
+ * I_out may be NULL: the field then stays on the device for sosrt_epilogue. */
 int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, const double* P0_aer,
                 double tol, const double* I1_in,
                 double* I_out, double* I_saved_out, int* n_orders_out, int* status_out);
@@ -116,6 +122,36 @@ int sosrt_last_solve_stats(sosrt_t* h, int* max_orders_run, long long* sum_order
 /* flux_down/up [B][L]; beam_norm 0: F0/(4 pi) (crit:380), 1: F0 (graphe:157). host pointers. */
 int sosrt_fluxes(sosrt_t* h, int B, const double* tau, const double* I, int beam_norm,
                  double* flux_down, double* flux_up);
+
+/* ---- epilogue on a RESIDENT field: what the reference's callers consume (a few kB per column instead of the
+ * 0.4-1.6 MB field).  flux_down / flux_up as sosrt_fluxes (graphe:157-158, crit:380-381); diffusivity
+ * -trapz(I mu, mu) / trapz(I, mu) per level (graphe:10); heating_rate per level (graphe:74-91, F0/(4 pi) beam
+ * terms, last level copied, the two levels at the slab boundaries overwritten as in 'erase_pics'; needs
+ * z_profile[L], the altitude grid np.linspace(z0, 0, L) of spec:39); net_toa [B] = -flux_down[0] - flux_up[0]
+ * with the F0/(4 pi) beam terms (crit:382).  The net flux of graphe:41 is flux_down + flux_up with beam_norm 1.
+ * Every output is nullable and skipped when NULL.
+ * _dev: all pointers are device pointers (d_z_profile [L]); enqueued on the handle's stream.
+ * sosrt_epilogue: works on the field and the optical depths the last sosrt_solve left in the handle (sosrt_solve
+ * accepts I_out == NULL for that), host z_profile and host outputs. */
+int sosrt_epilogue_dev(sosrt_t* h, int B, const double* d_tau, const double* d_I, int beam_norm,
+                       const double* d_z_profile, double* d_flux_down, double* d_flux_up, double* d_diffusivity,
+                       double* d_heating_rate, double* d_net_toa);
+int sosrt_epilogue(sosrt_t* h, int B, int beam_norm, const double* z_profile, double* flux_down, double* flux_up,
+                   double* diffusivity, double* heating_rate, double* net_toa);
+
+/* ---- inputs of the path built on the device: azimuth-averaged phase functions (phase:68-292) --------------- */
+#define SOSRT_PHASE_ISO       0   /* phase:68  isotropic                                                      */
+#define SOSRT_PHASE_RAYLEIGH  1   /* phase:79  rayleigh                                                       */
+#define SOSRT_PHASE_HG        2   /* phase:141 henyey_greenstein, asymmetry g                                 */
+#define SOSRT_PHASE_TABLE     3   /* phase:238 fwc: a tabulated p(cos Theta), linear interpolation phase:198  */
+/* table of SOSRT_PHASE_TABLE (host arrays, tab_mu ascending; fwc:3,173 is the reference's table) */
+int sosrt_phase_table(sosrt_t* h, const double* tab_mu, const double* tab_p, int ntab);
+/* P0(mu, mu0[b]) for B columns (phase:86-103): 25-point azimuth trapezoid, normalised to trapz(P0, mu) = 2.
+ * _dev: d_mu0 [B] and d_P0_out [B][2N] are device pointers (a mu0 sweep builds its P0 where the solve reads it). */
+int sosrt_phase_p0_dev(sosrt_t* h, int B, int kind, double g, const double* d_mu0, double* d_P0_out);
+int sosrt_phase_p0(sosrt_t* h, int B, int kind, double g, const double* mu0, double* P0_out);
+/* P(mu, mu') [2N][2N] row-major with the column normalisation trapz(P[:, n], mu) = 4 (phase:107-131); host output */
+int sosrt_phase_matrix(sosrt_t* h, int kind, double g, double* P_out);
 
 /* ---- helper level (In_limit:70,113) on device, host pointers -------------------------------- */
 /* rows [R][N] of downward radiances; returns the idx rewritten values per row: out [R][idx] with

@@ -475,6 +475,65 @@ def diffusivity(I, mu):
     return np.array([-_trapz(I[i] * mu, mu) / _trapz(I[i], mu) for i in range(I.shape[0])])
 
 
+def net_flux(I, mu, tau, N, mu0, grd_alb):
+    """graphe:41: one trapezoid over the whole direction grid, beam terms with F0."""
+    F0, L = np.pi / mu0, len(tau)
+    return np.array([_trapz(I[i] * mu, mu) - F0 * np.exp(-tau[i] / mu0) + grd_alb * F0 * np.exp(-(2 * tau[L - 1] - tau[i]) / mu0)
+                     for i in range(L)])
+
+
+def heating_rate(I, mu, tau, N, mu0, grd_alb, z_profile, idx_up, idx_down):
+    """graphe:70-91: -(1/(rho c_p)) d(flux_down + flux_up)/dz with the F0/(4 pi) beam terms, last level copied
+    from the one above, and the two levels at the slab boundaries overwritten by their upper neighbours
+    ('erase_pics', graphe:87-91)."""
+    rho, c_p = 1.225, 1004
+    fd, fu = fluxes(I, mu, tau, N, mu0, grd_alb, beam_norm="crit")
+    flux = fd + fu
+    L = len(tau)
+    hr = np.zeros(L)
+    for i in range(L - 1):
+        hr[i] = -(1 / (rho * c_p)) * (flux[i + 1] - flux[i]) / (z_profile[i + 1] - z_profile[i])
+    hr[-1] = hr[-2]
+    hr[idx_up - 1] = hr[idx_up - 2]
+    hr[idx_down] = hr[idx_down - 1]
+    return hr
+
+
+def toa_net_flux(I, mu, tau, N, mu0, grd_alb):
+    """crit:377-382."""
+    fd, fu = fluxes(I, mu, tau, N, mu0, grd_alb, beam_norm="crit")
+    return -fd[0] - fu[0]
+
+
+def radiative_forcing(col: "Column", baseline: Optional["Column"] = None, literal=False):
+    """crit:384-389.  As coded (`baseline=None`) the recursion for the aerosol-free term passes the same
+    optical-depth grid, mixing fractions and phase arrays, so it recomputes the same column and the
+    forcing is exactly 0.0.  With `baseline` (the column without the aerosol on its own grid)
+    it is the difference of the two net fluxes."""
+    f = toa_net_flux(solve_column(col, literal=literal).I, col.mu, col.tau, col.N, col.mu0, col.grd_alb)
+    if baseline is None:
+        return f - toa_net_flux(solve_column(col, literal=literal).I, col.mu, col.tau, col.N, col.mu0, col.grd_alb)
+    fb = toa_net_flux(solve_column(baseline, literal=literal).I, baseline.mu, baseline.tau, baseline.N, baseline.mu0,
+                      baseline.grd_alb)
+    return f - fb
+
+
+def critical_albedo(forcing_of_albedo, width=0.1, tol=0.001):
+    """The bisection of crit:394-410 on the aerosol single-scattering albedo; `forcing_of_albedo(w)` plays
+    SOS_Aer_radiative_forcing with alb_aer = w."""
+    alb_max, alb_min = 1, 0
+    while (alb_max - alb_min) > width:
+        test = (alb_max + alb_min) / 2
+        f = forcing_of_albedo(test)
+        if abs(f) < tol:
+            return test
+        if f > 0:
+            alb_min = test
+        else:
+            alb_max = test
+    return (alb_max + alb_min) / 2
+
+
 # ---------------------------------------------------------------------------
 # phase functions (phase:68-195), vectorised
 # ---------------------------------------------------------------------------
@@ -510,3 +569,20 @@ def phase_rayleigh(N, mu, mu0):
 def phase_hg(N, mu, mu0, g):
     """phase:141-195."""
     return _phase_pair(lambda c: (1 - g * g) / ((1 + g * g - 2 * g * c) ** 1.5), N, mu, mu0)
+
+
+def interpolate_table(mu_tab, p_tab, c):
+    """phase:198-236 (interpolate_fwc_phase), vectorised: clip to [-1, 1], `idx = searchsorted(mu_tab, c)`
+    (left), table ends returned as they are, linear interpolation between idx-1 and idx otherwise."""
+    c = np.clip(c, -1, 1)
+    idx = np.searchsorted(mu_tab, c)
+    lo = np.clip(idx - 1, 0, len(mu_tab) - 1)
+    hi = np.clip(idx, 0, len(mu_tab) - 1)
+    w = (c - mu_tab[lo]) / np.where(hi == lo, 1.0, mu_tab[hi] - mu_tab[lo])
+    v = p_tab[lo] + w * (p_tab[hi] - p_tab[lo])
+    return np.where(idx == 0, p_tab[0], np.where(idx >= len(mu_tab), p_tab[-1], v))
+
+
+def phase_table(N, mu, mu0, mu_tab, p_tab):
+    """phase:238-292 (fwc) for any tabulated phase function (fwc:3,173 is the reference's table)."""
+    return _phase_pair(lambda c: interpolate_table(mu_tab, p_tab, c), N, mu, mu0)

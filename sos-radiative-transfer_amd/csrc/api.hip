@@ -39,6 +39,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int kProfPool = 8192;
+constexpr int kNPhi = 25;                // phase:81  nb_phi
 
 // HIP-event timing of launch groups.  An interval is a pair of events of the pool; when one bracket
 // closes and the next opens with nothing enqueued in between (the order loop: contraction, transport,
@@ -55,6 +56,7 @@ struct Prof {
 
 struct sosrt_handle {
     int device = -1, L = 0, N = 0, D = 0, max_batch = 0, max_orders = 0;
+    int saved_slots = 0;                 // orders per column in I_saved_out (sosrt_set_saved_orders; default max_orders)
     bool gpu = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
     Plan plan;
@@ -64,6 +66,12 @@ struct sosrt_handle {
     Grid g{};
     // device: grid / phase
     double *d_mu = nullptr, *d_Wa = nullptr, *d_Wr = nullptr, *d_wfdn = nullptr, *d_wfup = nullptr;
+    double *d_w = nullptr;               // [D] np.trapz weights on the whole grid
+    double *d_phi = nullptr;             // [2][kNPhi] cos(phi), trapz weights of phi = linspace(0, pi, kNPhi) (phase:81-82)
+    double *d_z = nullptr;               // [L] altitude grid of the host epilogue
+    double *d_tab = nullptr;             // [2][ntab] table of SOSRT_PHASE_TABLE
+    int ntab = 0;
+    bool resident = false;               // d_tau / d_I hold the inputs / result of the last sosrt_solve
     FixTab* d_fix = nullptr;
     int* d_small = nullptr;
     // device: columns
@@ -81,6 +89,7 @@ struct sosrt_handle {
     bool mix_dirty = true;
     double *d_Wmix = nullptr, *d_mixca = nullptr, *d_mixcr = nullptr;
     int* d_mixgroup = nullptr;
+    int* d_slabtilegroup = nullptr;      // [tiles] group of every 32-row slab tile of the dense contraction
     size_t mix_capacity = 0;
     // device: fields (internal)
     double *d_tau = nullptr, *d_P0a = nullptr, *d_P0r = nullptr;
@@ -219,11 +228,18 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
     ga.rows_slab = h->d_slabrows; ga.n_slab = h->nslab;
     ga.D = h->g.D; ga.Dp = h->g.Dp; ga.Wld = h->g.Wld; ga.L = h->L; ga.C = Jn; ga.active = active;
     if (pub_tag) { ga.nactive = h->d_nactive; ga.host_pub = h->h_pub; ga.tag = pub_tag; }
+    if (h->mix_groups > 0) {
+        if (h->mix_dirty) {
+            prof_break(h);
+            launch_wmix(h->stream, (size_t)h->g.Dp * h->g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
+            h->mix_dirty = false;
+        }
+        ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; ga.slab_tile_group = h->d_slabtilegroup;
+    }
     prof_begin(h, SOSRT_K_GEMM);
     if (tail_cols > 0 && active) {
         ga.B = h->B; ga.max_main = h->max_main; ga.max_slab = h->max_slab;
         ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
-        if (h->mix_groups > 0 && !h->mix_dirty) { ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; }
         launch_gemm_tail(h->stream, ga, tail_cols, tail_cols <= h->gemm_small_cols);
     } else {
         launch_gemm(h->stream, ga);
@@ -250,6 +266,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     sosrt_handle* h = new (std::nothrow) sosrt_handle();
     if (!h) return fail(SOSRT_E_NOMEM, "out of host memory");
     h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;
+    h->saved_slots = max_orders;
     h->gpu = device >= 0;
     if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
@@ -258,7 +275,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_LOADERS")) g_ring_loaders = atoi(ev);
-    if (const char* ev = getenv("SOSRT_RING_DEBUG")) g_ring_debug = atoi(ev);   // timing experiments, see transport_ring.hip
+#ifdef SOSRT_RING_DEBUG   // diagnostic builds only: the switches make the ring kernel skip work, its results are wrong
+    if (const char* ev = getenv("SOSRT_RING_DEBUG")) g_ring_debug = atoi(ev);
+#endif
     Grid& g = h->g;
     g.L = L; g.N = N; g.D = 2 * N;
     g.Dp = (g.D + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
@@ -275,6 +294,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_Wr, (size_t)g.Dp * g.Wld))) return e;
             if ((e = dalloc(&h->d_wfdn, N))) return e;
             if ((e = dalloc(&h->d_wfup, N))) return e;
+            if ((e = dalloc(&h->d_w, g.D))) return e;
+            if ((e = dalloc(&h->d_phi, 2 * kNPhi))) return e;
+            if ((e = dalloc(&h->d_z, L))) return e;
             if ((e = dalloc(&h->d_fix, 4))) return e;
             if ((e = dalloc(&h->d_small, N))) return e;
             if ((e = dalloc(&h->d_idx_up, mb))) return e;
@@ -283,7 +305,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_desc, mb))) return e;
             if ((e = dalloc(&h->d_rca, mb * L))) return e;
             if ((e = dalloc(&h->d_rcr, mb * L))) return e;
-            if ((e = dalloc(&h->d_slabrows, mb * L))) return e;
+            if ((e = dalloc(&h->d_slabrows, mb * L + 32 * (size_t)sosrt_handle::kMaxMixGroups))) return e;   // + padding per group
+            if ((e = dalloc(&h->d_slabtilegroup, mb * L / 32 + sosrt_handle::kMaxMixGroups + 1))) return e;
             if ((e = dalloc(&h->d_mainrows, mb * L))) return e;
             if ((e = dalloc(&h->d_tau, mb * L))) return e;
             if ((e = dalloc(&h->d_P0a, mb * g.D))) return e;
@@ -331,7 +354,7 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup};
+                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -346,6 +369,13 @@ int sosrt_destroy(sosrt_t* h) {
 int sosrt_set_stream(sosrt_t* h, void* s) {
     if (int e = need_gpu(h)) return e;
     h->stream = s ? (hipStream_t)s : h->own_stream;
+    return 0;
+}
+
+int sosrt_set_saved_orders(sosrt_t* h, int slots) {
+    if (!h) return fail(SOSRT_E_INVALID, "null handle");
+    if (slots < 1 || slots > h->max_orders) return fail(SOSRT_E_INVALID, "slots must be in 1..max_orders=%d (got %d)", h->max_orders, slots);
+    h->saved_slots = slots;
     return 0;
 }
 
@@ -374,6 +404,18 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
         HIPCHK(hipMemcpy(h->d_mu, mu, h->D * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_wfdn, h->plan.wflux_dn.data(), h->N * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_wfup, h->plan.wflux_up.data(), h->N * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_w, h->plan.w.data(), h->D * sizeof(double), hipMemcpyHostToDevice));
+        {   // phi = np.linspace(0, pi, 25) (phase:81-82): cos(phi0 - phi) and the trapezoid weights of np.trapz(., phi)
+            double phi[kNPhi], tab[2 * kNPhi];
+            const double step = 3.141592653589793 / (kNPhi - 1);
+            for (int q = 0; q < kNPhi; ++q) phi[q] = q * step;
+            phi[kNPhi - 1] = 3.141592653589793;
+            for (int q = 0; q < kNPhi; ++q) {
+                tab[q] = std::cos(0 - phi[q]);
+                tab[kNPhi + q] = ((q > 0 ? phi[q] - phi[q - 1] : 0.0) + (q + 1 < kNPhi ? phi[q + 1] - phi[q] : 0.0)) / 2;
+            }
+            HIPCHK(hipMemcpy(h->d_phi, tab, sizeof tab, hipMemcpyHostToDevice));
+        }
         std::vector<FixTab> ft(4);
         for (int b = 0; b < 4; ++b) {
             const FixTable& t = h->plan.fix[b];
@@ -499,6 +541,18 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
                 HIPCHK(hipMemcpy(h->d_mixcr, gcr.data(), gcr.size() * sizeof(double), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(h->d_mixgroup, gid.data(), B * sizeof(int), hipMemcpyHostToDevice));
                 h->mix_groups = (int)gca.size();
+                // slab rows of the dense contraction listed group by group, every group padded to whole 32-row tiles
+                std::vector<int> grouped, tilegroup;
+                for (int k = 0; k < h->mix_groups; ++k) {
+                    for (int b = 0; b < B; ++b)
+                        if (gid[b] == k)
+                            for (int t = idx_up[b]; t <= idx_down[b]; ++t) grouped.push_back(b * h->L + t);
+                    while (grouped.size() % 32) grouped.push_back(-1);
+                    while (tilegroup.size() < grouped.size() / 32) tilegroup.push_back(k);
+                }
+                HIPCHK(hipMemcpy(h->d_slabrows, grouped.data(), grouped.size() * sizeof(int), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_slabtilegroup, tilegroup.data(), tilegroup.size() * sizeof(int), hipMemcpyHostToDevice));
+                h->nslab = (int)grouped.size();
             }
         }
     }
@@ -619,14 +673,10 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     hipStream_t s = h->stream;
     const Grid& g = h->g;
     const size_t LD = (size_t)h->L * h->D;
-    const size_t saved_stride = (size_t)h->max_orders * LD;
+    const size_t saved_stride = (size_t)h->saved_slots * LD;
     Conv cv = make_conv(h, tol);
 
     prof_break(h);
-    if (h->mix_groups > 0 && h->mix_dirty) {
-        launch_wmix(s, (size_t)g.Dp * g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
-        h->mix_dirty = false;
-    }
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, 2 * sizeof(int), s));
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr, h->d_nactive + 1);
     h->need_small = true;
@@ -673,7 +723,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             prof_end(h, SOSRT_K_SMALLMU);
         }
         prof_begin(h, SOSRT_K_TRANSPORT);
-        double* sv_n = d_I_saved_out ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr;
+        double* sv_n = (d_I_saved_out && n <= h->saved_slots) ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr;
         if (fast) {
             // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
             // need not stage those rows either
@@ -701,9 +751,10 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
 int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, const double* P0_aer, double tol,
                 const double* I1_in, double* I_out, double* I_saved_out, int* n_orders_out, int* status_out) {
     if (int e = check_ready(h, B, true)) return e;
-    if (!tau || !I_out) return fail(SOSRT_E_INVALID, "null argument");
+    if (!tau) return fail(SOSRT_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
+    h->resident = false;
     const size_t LD = (size_t)h->L * h->D, n = (size_t)B * LD;
     HIPCHK(hipMemcpyAsync(h->d_tau, tau, (size_t)B * h->L * sizeof(double), hipMemcpyHostToDevice, s));
     if (P0_atm) HIPCHK(hipMemcpyAsync(h->d_P0a, P0_atm, (size_t)B * h->D * sizeof(double), hipMemcpyHostToDevice, s));
@@ -717,15 +768,15 @@ int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, cons
             HIPCHK(hipMemcpyAsync(d_I1, I1_in, n * sizeof(double), hipMemcpyHostToDevice, s));
         }
         if (I_saved_out) {
-            if (int e = dalloc(&d_saved, (size_t)B * h->max_orders * LD)) return e;
-            HIPCHK(hipMemsetAsync(d_saved, 0, (size_t)B * h->max_orders * LD * sizeof(double), s));
+            if (int e = dalloc(&d_saved, (size_t)B * h->saved_slots * LD)) return e;
+            HIPCHK(hipMemsetAsync(d_saved, 0, (size_t)B * h->saved_slots * LD * sizeof(double), s));
         }
         if (int e = sosrt_solve_dev(h, B, h->d_tau, P0_atm ? h->d_P0a : nullptr, P0_aer ? h->d_P0r : nullptr, tol, d_I1,
                                     h->d_I, d_saved, nullptr, nullptr))
             return e;
-        HIPCHK(hipMemcpyAsync(I_out, h->d_I, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (I_out) HIPCHK(hipMemcpyAsync(I_out, h->d_I, n * sizeof(double), hipMemcpyDeviceToHost, s));
         if (I_saved_out)
-            HIPCHK(hipMemcpyAsync(I_saved_out, d_saved, (size_t)B * h->max_orders * LD * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(I_saved_out, d_saved, (size_t)B * h->saved_slots * LD * sizeof(double), hipMemcpyDeviceToHost, s));
         std::vector<int> no(B);
         HIPCHK(hipMemcpyAsync(no.data(), h->d_norders, B * sizeof(int), hipMemcpyDeviceToHost, s));
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, h->d_status, B * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -733,6 +784,7 @@ int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, cons
         long long sum = 0;
         for (int b = 0; b < B; ++b) { sum += no[b] - 1; if (n_orders_out) n_orders_out[b] = no[b]; }
         h->last_sum_orders = sum;
+        h->resident = true;
         return 0;
     };
     rc = body();
@@ -772,6 +824,121 @@ int sosrt_fluxes(sosrt_t* h, int B, const double* tau, const double* I, int beam
     HIPCHK(hipMemcpyAsync(flux_up, h->d_rcr, r * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// epilogue on a resident field
+// ---------------------------------------------------------------------------------------------
+int sosrt_epilogue_dev(sosrt_t* h, int B, const double* d_tau, const double* d_I, int beam_norm, const double* d_z_profile,
+                       double* d_flux_down, double* d_flux_up, double* d_diffusivity, double* d_heating_rate,
+                       double* d_net_toa) {
+    if (int e = check_ready(h, B, false)) return e;
+    if (!d_tau || !d_I) return fail(SOSRT_E_INVALID, "null argument");
+    if (d_heating_rate && !d_z_profile) return fail(SOSRT_E_INVALID, "the heating rate needs z_profile");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    launch_prepare(s, h->g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr);
+    EpilogueOut out{d_flux_down, d_flux_up, d_diffusivity, d_heating_rate, d_net_toa};
+    launch_epilogue(s, h->g, h->d_w, B, d_tau, d_I, h->d_desc, beam_norm, d_z_profile, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int sosrt_epilogue(sosrt_t* h, int B, int beam_norm, const double* z_profile, double* flux_down, double* flux_up,
+                   double* diffusivity, double* heating_rate, double* net_toa) {
+    if (int e = check_ready(h, B, false)) return e;
+    if (!h->resident) return fail(SOSRT_E_STATE, "no resident field: call sosrt_solve first");
+    if (heating_rate && !z_profile) return fail(SOSRT_E_INVALID, "the heating rate needs z_profile");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t r = (size_t)B * h->L;
+    if (4 * r + B > field_elems(h)) return fail(SOSRT_E_INVALID, "batch too large for the scratch buffer");
+    if (z_profile) HIPCHK(hipMemcpyAsync(h->d_z, z_profile, h->L * sizeof(double), hipMemcpyHostToDevice, s));
+    double* o = h->d_Jn;                                     // scratch: the source function of the last order is dead
+    if (int e = sosrt_epilogue_dev(h, B, h->d_tau, h->d_I, beam_norm, z_profile ? h->d_z : nullptr, flux_down ? o : nullptr,
+                                   flux_up ? o + r : nullptr, diffusivity ? o + 2 * r : nullptr,
+                                   heating_rate ? o + 3 * r : nullptr, net_toa ? o + 4 * r : nullptr))
+        return e;
+    if (flux_down) HIPCHK(hipMemcpyAsync(flux_down, o, r * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (flux_up) HIPCHK(hipMemcpyAsync(flux_up, o + r, r * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (diffusivity) HIPCHK(hipMemcpyAsync(diffusivity, o + 2 * r, r * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (heating_rate) HIPCHK(hipMemcpyAsync(heating_rate, o + 3 * r, r * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (net_toa) HIPCHK(hipMemcpyAsync(net_toa, o + 4 * r, B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase functions on the device
+// ---------------------------------------------------------------------------------------------
+int sosrt_phase_table(sosrt_t* h, const double* tab_mu, const double* tab_p, int ntab) {
+    if (int e = need_gpu(h)) return e;
+    if (!tab_mu || !tab_p || ntab < 2) return fail(SOSRT_E_INVALID, "a table needs at least two points");
+    for (int i = 1; i < ntab; ++i)
+        if (!(tab_mu[i] > tab_mu[i - 1])) return fail(SOSRT_E_INVALID, "tab_mu must be strictly ascending (index %d)", i);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_tab) { hipFree(h->d_tab); h->d_tab = nullptr; h->ntab = 0; }
+    if (int e = dalloc(&h->d_tab, 2 * (size_t)ntab)) return e;
+    HIPCHK(hipMemcpy(h->d_tab, tab_mu, ntab * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_tab + ntab, tab_p, ntab * sizeof(double), hipMemcpyHostToDevice));
+    h->ntab = ntab;
+    return 0;
+}
+
+static int phase_check(sosrt_handle* h, int kind, double g) {
+    if (int e = need_gpu(h)) return e;
+    if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
+    if (kind < SOSRT_PHASE_ISO || kind > SOSRT_PHASE_TABLE) return fail(SOSRT_E_INVALID, "unknown phase-function kind %d", kind);
+    if (kind == SOSRT_PHASE_TABLE && !h->d_tab) return fail(SOSRT_E_STATE, "sosrt_phase_table has not been called");
+    if (kind == SOSRT_PHASE_HG && !(std::fabs(g) < 1)) return fail(SOSRT_E_INVALID, "|g| must be < 1 (got %g)", g);
+    return 0;
+}
+
+int sosrt_phase_p0_dev(sosrt_t* h, int B, int kind, double g, const double* d_mu0, double* d_P0_out) {
+    if (int e = phase_check(h, kind, g)) return e;
+    if (B < 1 || !d_mu0 || !d_P0_out) return fail(SOSRT_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    launch_phase_p0(h->stream, h->g, h->d_w, B, kind, g, h->d_tab, h->d_tab ? h->d_tab + h->ntab : nullptr, h->ntab, h->d_phi,
+                    h->d_phi + kNPhi, kNPhi, d_mu0, d_P0_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int sosrt_phase_p0(sosrt_t* h, int B, int kind, double g, const double* mu0, double* P0_out) {
+    if (int e = phase_check(h, kind, g)) return e;
+    if (B < 1 || B > h->max_batch || !mu0 || !P0_out) return fail(SOSRT_E_INVALID, "bad argument (B must be 1..max_batch)");
+    for (int b = 0; b < B; ++b)
+        if (!(mu0[b] > 0 && mu0[b] <= 1)) return fail(SOSRT_E_INVALID, "column %d: mu0 must be in (0, 1]", b);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_ratio, mu0, B * sizeof(double), hipMemcpyHostToDevice, s));
+    if (int e = sosrt_phase_p0_dev(h, B, kind, g, h->d_ratio, h->d_P0a)) return e;
+    HIPCHK(hipMemcpyAsync(P0_out, h->d_P0a, (size_t)B * h->D * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int sosrt_phase_matrix(sosrt_t* h, int kind, double g, double* P_out) {
+    if (int e = phase_check(h, kind, g)) return e;
+    if (!P_out) return fail(SOSRT_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    double* dP = nullptr;
+    const size_t n = (size_t)h->D * h->D;
+    if (int e = dalloc(&dP, n)) return e;
+    int rc = 0;
+    auto body = [&]() -> int {
+        launch_phase_matrix(s, h->g, h->d_w, kind, g, h->d_tab, h->d_tab ? h->d_tab + h->ntab : nullptr, h->ntab, h->d_phi,
+                            h->d_phi + kNPhi, kNPhi, dP);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(P_out, dP, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    };
+    rc = body();
+    hipFree(dP);
+    return rc;
 }
 
 int sosrt_limit_mu_down(sosrt_t* h, int R, int idx, const double* rows, double* out) {

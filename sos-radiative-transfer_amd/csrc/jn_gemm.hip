@@ -33,7 +33,7 @@ constexpr int B_LD = GEMM_BN + 16;
 struct ListRows {               // the host-built row lists over all columns (null list: identity)
     const int* rows;
     int n;
-    __device__ int operator()(int lr) const { return lr < n ? (rows ? rows[lr] : lr) : -1; }
+    __device__ int operator()(int lr) const { return lr < n ? (rows ? rows[lr] : lr) : -1; }   // a list may hold -1 (padding)
 };
 struct ColumnRows {             // the plain or the slab rows of one column
     int base, iu, ns, n;        // b*L, first slab row, slab rows, rows of this kind
@@ -236,8 +236,18 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     const int id = blockIdx.x;
     const int tile = (id / (8 * nct)) * 8 + (id & 7), bn0 = ((id >> 3) % nct) * GEMM_BN;
     if (tile >= tiles) return;
-    if (tile < tiles_main) gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, tile, bn0, ListRows{g.rows_main, g.n_main}, true);
-    else gemm_tile<2, true>(g, sA, sB, &s_any, tile - tiles_main, bn0, ListRows{g.rows_slab, g.n_slab}, true);
+    if (tile < tiles_main) {
+        gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, tile, bn0, ListRows{g.rows_main, g.n_main}, true);
+    } else if (g.Wmix && g.slab_tile_group) {
+        // the slab rows are listed group by group (one distinct coefficient pair per 32-row tile): one pass over the
+        // group's combined matrix, the same arithmetic as the live-column tilings (a column's result does not
+        // depend on which tiling, or which batch, it was computed in)
+        const int st = tile - tiles_main;
+        gemm_tile<2, false>(g, sA, sB, &s_any, st, bn0, ListRows{g.rows_slab, g.n_slab}, true,
+                            g.Wmix + (size_t)g.slab_tile_group[st] * g.Dp * g.Wld);
+    } else {
+        gemm_tile<2, true>(g, sA, sB, &s_any, tile - tiles_main, bn0, ListRows{g.rows_slab, g.n_slab}, true);
+    }
 }
 
 // The same contraction once some columns have converged.  Tiling the row lists would launch a

@@ -135,6 +135,7 @@ struct GemmArgs {
     int max_main = 0, max_slab = 0;  // most plain / slab rows any column has
     const double* Wmix = nullptr;    // [groups][Dp][Wld] ca W_atm + cr W_aer per distinct slab coefficient pair; null: two passes
     const int* mix_group = nullptr;  // [B] group of a column
+    const int* slab_tile_group = nullptr;   // dense kernel: group of every 32-row tile of rows_slab (listed group by group, padded with -1)
     // The order loop's view of the batch: the first workgroup of the source-function launch of order
     // n+1 (which starts when order n has finished) writes {live columns after order n, tag} to pinned
     // host memory, where the host spins on the tag -- no copy, no event, no stream drain.
@@ -170,6 +171,23 @@ void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, 
 void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep);
 void launch_fluxes(hipStream_t s, const Grid& g, int B, const double* tau, const double* I, const ColDesc* desc,
                    int beam_norm, double* fdn, double* fup);
+// epilogue.hip: outputs of the epilogue (each nullable): [B][L] per level, net_toa [B]
+struct EpilogueOut {
+    double* flux_down;
+    double* flux_up;
+    double* diffusivity;
+    double* heating_rate;
+    double* net_toa;
+};
+// w: np.trapz weights on the whole direction grid [D]; z_profile [L] (nullable: no heating rate)
+void launch_epilogue(hipStream_t s, const Grid& g, const double* w, int B, const double* tau, const double* I,
+                     const ColDesc* desc, int beam_norm, const double* z_profile, const EpilogueOut& out);
+// phase functions on the device; cosphi / wphi: cos(phi) and trapz weights of phi = linspace(0, pi, nphi)
+void launch_phase_p0(hipStream_t s, const Grid& g, const double* w, int B, int kind, double gpar, const double* tab_mu,
+                     const double* tab_p, int ntab, const double* cosphi, const double* wphi, int nphi,
+                     const double* mu0, double* P0);
+void launch_phase_matrix(hipStream_t s, const Grid& g, const double* w, int kind, double gpar, const double* tab_mu,
+                         const double* tab_p, int ntab, const double* cosphi, const double* wphi, int nphi, double* P);
 void launch_limit_rows(hipStream_t s, const Grid& g, int R, int table, const double* rows, double* out);
 void launch_asymptotic(hipStream_t s, int R, int stride, const int* len, const double* J, const double* tau,
                        const double* tau_t, const double* mu, double* out);

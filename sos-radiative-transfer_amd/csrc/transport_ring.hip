@@ -46,7 +46,13 @@ __device__ __forceinline__ void wg_barrier() {
 }
 
 template <bool ACC, bool SAVED, int PIECES>
-__global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int NWL, int dbg) {
+__global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int NWL, int dbg_arg) {
+#ifdef SOSRT_RING_DEBUG
+    const int dbg = dbg_arg;            // diagnostic builds only (-DSOSRT_RING_DEBUG): timing switches that corrupt the results
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     const int b = blockIdx.x;
     if (ACC && !a.cv.active[b]) return;
     const Grid& g = a.g;

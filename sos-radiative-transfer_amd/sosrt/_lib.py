@@ -15,6 +15,7 @@ COL_OK, COL_INDEXERROR, COL_MAXORDERS = 0, 1, 2
 GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
 SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN = 0, 1, 2
 K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU = 0, 1, 2, 3
+PHASE_ISO, PHASE_RAYLEIGH, PHASE_HG, PHASE_TABLE = 0, 1, 2, 3
 
 _dp = POINTER(c_double)
 _ip = POINTER(c_int)
@@ -27,6 +28,7 @@ SIGNATURES = {
     "sosrt_destroy": (c_int, [c_void_p]),
     "sosrt_set_stream": (c_int, [c_void_p, c_void_p]),
     "sosrt_synchronize": (c_int, [c_void_p]),
+    "sosrt_set_saved_orders": (c_int, [c_void_p, c_int]),
     "sosrt_set_grid": (c_int, [c_void_p, c_void_p]),
     "sosrt_set_phase": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sosrt_set_columns": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 9),
@@ -37,6 +39,12 @@ SIGNATURES = {
     "sosrt_solve_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sosrt_last_solve_stats": (c_int, [c_void_p, _ip, POINTER(c_longlong)]),
     "sosrt_fluxes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "sosrt_epilogue_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 6),
+    "sosrt_epilogue": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),
+    "sosrt_phase_table": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "sosrt_phase_p0_dev": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "sosrt_phase_p0": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "sosrt_phase_matrix": (c_int, [c_void_p, c_int, c_double, c_void_p]),
     "sosrt_limit_mu_down": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sosrt_asymptotic_down": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sosrt_plan_weights": (c_int, [c_void_p, c_void_p]),

@@ -1,16 +1,41 @@
 """Inputs of the hot path: optical-depth grid, direction grid, phase functions.
 
-These are host-side (NumPy) builders for the arrays the reference's drivers
-construct before the order loop (SOS_Aer_tau_profile.py, SOS_Aer_phase_func.py);
-they are not on the timed path.  'iso', 'rayleigh' and 'hg' are pinned to the
-reference's outputs (tests/golden/g5_*).  The Mie-derived functions ('mie',
-'eva', 'wildfire') follow the reference's recipe on top of this package's own
-Mie series (sosrt/mie.py) because `miepython` is not available offline: their
-parity is unpinned.
+Builders for the arrays the reference's drivers construct before the order loop
+(SOS_Aer_tau_profile.py, SOS_Aer_phase_func.py).  'iso', 'rayleigh', 'hg' and 'fwc' are
+pinned to the reference's outputs at N = 32 and N = 128 (tests/golden/g5_*).  The
+Mie-derived functions ('mie', 'eva', 'wildfire') follow the reference's recipe on top of
+this package's own Mie series (sosrt/mie.py) because `miepython` is not available offline:
+their parity is unpinned.
+
+`phase_function(...)` is the host (NumPy) builder; `phase_function_device(...)` evaluates
+the same azimuth averages with the HIP kernels of csrc/epilogue.hip -- P0(mu, mu0) for a
+whole array of mu0 at once (a mu0 sweep needs a fresh P0 per column) and P(mu, mu').
 """
+import os
+
 import numpy as np
 
 from . import mie as _mie
+
+_FWC_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "fwc_table.npz")
+
+
+def fwc_table():
+    """(mu_fwc, phase_func_FWC): the tabulated fair-weather-cumulus phase function of SOS_Aer_fwc_data.py:3,173
+    (1001 points on cos(Theta) = -1..1); data file written by tests/golden/make_golden.py."""
+    d = np.load(_FWC_TABLE)
+    return d["mu_fwc"], d["phase_func_FWC"]
+
+
+def interpolate_table(mu_tab, p_tab, c):
+    """SOS_Aer_phase_func.py:198-236 (interpolate_fwc_phase), vectorised."""
+    c = np.clip(c, -1, 1)
+    idx = np.searchsorted(mu_tab, c)
+    lo = np.clip(idx - 1, 0, len(mu_tab) - 1)
+    hi = np.clip(idx, 0, len(mu_tab) - 1)
+    w = (c - mu_tab[lo]) / np.where(hi == lo, 1.0, mu_tab[hi] - mu_tab[lo])
+    v = p_tab[lo] + w * (p_tab[hi] - p_tab[lo])
+    return np.where(idx == 0, p_tab[0], np.where(idx >= len(mu_tab), p_tab[-1], v))
 
 _trapz = getattr(np, "trapezoid", None) or np.trapz
 
@@ -64,25 +89,56 @@ def _bulk(name, **kw):
     return _bulk_cache[key]
 
 
-def phase_function(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None):
-    """'iso' | 'rayleigh' | 'hg' (SOS_Aer_phase_func.py:68,79,141); 'mie' (one sphere of radius r, :299);
-    'eva' | 'wildfire' (log-normal ensemble, :398; parameters default to the README's scenarios)."""
-    if name == "iso":
-        return np.ones(2 * nb_angles), 2 * np.ones((2 * nb_angles, 2 * nb_angles))
+def _scalar_phase(name, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None):
+    """p(cos Theta) as a NumPy callable, and -- for the device builders -- its (kind, table) form."""
     if name == "rayleigh":
-        return _azimuth_averaged(lambda c: (3 / 4) * (1 + c * c), mu, mu0)
+        return (lambda c: (3 / 4) * (1 + c * c)), ("rayleigh", None)
     if name == "hg":
-        return _azimuth_averaged(lambda c: (1 - g * g) / ((1 + g * g - 2 * g * c) ** 1.5), mu, mu0)
+        return (lambda c: (1 - g * g) / ((1 + g * g - 2 * g * c) ** 1.5)), ("hg", None)
+    if name == "fwc" or name == "table":
+        mt, pt = fwc_table() if table is None else (np.asarray(table[0], dtype=np.float64), np.asarray(table[1], dtype=np.float64))
+        return (lambda c: interpolate_table(mt, pt, c)), ("table", (mt, pt))
     if name in ("eva", "wildfire"):
         kw = dict(_mie.SCENARIOS[name])
         for k, v in (("wl", lambda0), ("m", indx), ("r_m", r_m), ("sig", sig)):
             if v:
                 kw[k] = v
-        return _azimuth_averaged(_bulk(name, **kw), mu, mu0)
+        return _bulk(name, **kw), None
     if name == "mie":
         if not (r and lambda0 and indx):
             raise ValueError("'mie' needs r, lambda0 and indx")
         x = 2 * np.pi * r / lambda0
         mu_d = np.linspace(-1, 1, 6001)
-        return _azimuth_averaged(_mie.tabulated_phase(mu_d, _mie.i_unpolarized(complex(indx), x, mu_d)), mu, mu0)
+        return _mie.tabulated_phase(mu_d, _mie.i_unpolarized(complex(indx), x, mu_d)), None
     raise ValueError("unknown phase function %r" % (name,))
+
+
+def phase_function(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None):
+    """'iso' | 'rayleigh' | 'hg' | 'fwc' (SOS_Aer_phase_func.py:68,79,141,238; 'table' = 'fwc' with a caller's
+    (mu_tab, p_tab)); 'mie' (one sphere of radius r, :299); 'eva' | 'wildfire' (log-normal ensemble, :398;
+    parameters default to the README's scenarios).  Host (NumPy) evaluation."""
+    if name == "iso":
+        return np.ones(2 * nb_angles), 2 * np.ones((2 * nb_angles, 2 * nb_angles))
+    fn, _ = _scalar_phase(name, g, r, lambda0, indx, r_m, sig, table)
+    return _azimuth_averaged(fn, mu, mu0)
+
+
+def phase_function_device(name, nb_angles, mu, mu0, g=0.0, table=None, matrix=True, device=0, solver=None):
+    """The same on the GPU: `mu0` may be an array (one P0 row per column).  Returns (P0 [len(mu0), 2N] or [2N] for a
+    scalar mu0, P [2N, 2N] or None when matrix=False).  'iso' | 'rayleigh' | 'hg' | 'fwc' | 'table'."""
+    from .solver import Solver
+    scalar = np.ndim(mu0) == 0
+    m = np.atleast_1d(np.asarray(mu0, dtype=np.float64))
+    kind, tab = ("iso", None) if name == "iso" else _scalar_phase(name, g, table=table)[1]
+    s = solver or Solver(2, nb_angles, max_batch=max(1, min(m.size, 4096)), max_orders=1, device=device)
+    try:
+        if not s.same_grid(mu):
+            s.set_grid(mu)
+        if tab is not None:
+            s.set_phase_table(*tab)
+        P0 = s.phase_p0(kind, m, g)
+        P = s.phase_matrix(kind, g) if matrix else None
+    finally:
+        if solver is None:
+            s.close()
+    return (P0[0] if scalar else P0), P

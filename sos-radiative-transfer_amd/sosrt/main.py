@@ -73,9 +73,24 @@ def _raise_status(status, nb_angles):
 def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, alb_aer=1.0, z0=120, z_up=25, z_down=17,
                   nb_layers=200, nb_angles=128, atm_phase_fun="rayleigh", g_atm=0.0, aer_phase_fun="hg", g_aer=0.7,
                   P_atm=None, P_aer=None, P0_atm=None, P0_aer=None, surface="specular", tol=1e-4, max_orders=256,
-                  save_orders=False, device=0, raise_on_error=True) -> BatchResult:
+                  save_orders=False, device=0, devices=None, raise_on_error=True) -> BatchResult:
     """Solve B independent columns (arrays mu0, tauStar_aer, grd_alb broadcast to a common length;
-    tauStar_atm, alb_atm, alb_aer may be arrays too)."""
+    tauStar_atm, alb_atm, alb_aer may be arrays too).  `devices=[0, 1, ...]` shards the columns over several
+    GPUs of the node, one worker process each, and gathers the fields (sosrt.dist.solve_on_devices; per-order
+    fields are not gathered)."""
+    if devices is not None and len(devices) > 1:
+        if save_orders:
+            raise ValueError("save_orders is not available with devices=[...]")
+        from .dist import solve_on_devices
+        r = solve_on_devices(devices, mu0, tauStar_aer, grd_alb, tauStar_atm=tauStar_atm, alb_atm=alb_atm, alb_aer=alb_aer,
+                             z0=z0, z_up=z_up, z_down=z_down, nb_layers=nb_layers, nb_angles=nb_angles,
+                             atm_phase_fun=atm_phase_fun, g_atm=g_atm, aer_phase_fun=aer_phase_fun, g_aer=g_aer, P_atm=P_atm,
+                             P_aer=P_aer, P0_atm=P0_atm, P0_aer=P0_aer, surface=surface, tol=tol, max_orders=max_orders)
+        if raise_on_error:
+            _raise_status(r.status, int(nb_angles))
+        return r
+    if devices is not None and len(devices) == 1:
+        device = int(devices[0])
     mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer = np.broadcast_arrays(
         *[np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in (mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer)])
     B = mu0.shape[0]

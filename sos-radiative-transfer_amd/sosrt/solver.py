@@ -40,7 +40,7 @@ class SolveResult:
     I: np.ndarray                  # [B, L, 2N]
     n: np.ndarray                  # [B] final order count (spec:307-310)
     status: np.ndarray             # [B] SOSRT_COL_*
-    I_saved: Optional[np.ndarray]  # [B, max_orders, L, 2N] (slots >= n[b] are zero) or None
+    I_saved: Optional[np.ndarray]  # [B, max(n), L, 2N] (slots >= n[b] are zero) or None
 
 
 class Solver:
@@ -146,18 +146,31 @@ class Solver:
         return out, st
 
     # ---- column level --------------------------------------------------------
-    def solve(self, tau, P0_atm=None, P0_aer=None, tol=1e-4, I1=None, save_orders=False) -> SolveResult:
+    def solve(self, tau, P0_atm=None, P0_aer=None, tol=1e-4, I1=None, save_orders=False, fetch_field=True) -> SolveResult:
+        """fetch_field=False leaves the radiance field on the device (SolveResult.I is None) for `epilogue`."""
         B = self.B
         tau = _f64(tau, (B, self.L), "tau")
         Pa = None if P0_atm is None else _f64(P0_atm, (B, self.D), "P0_atm")
         Pr = None if P0_aer is None else _f64(P0_aer, (B, self.D), "P0_aer")
         I1a = None if I1 is None else _f64(I1, (B, self.L, self.D), "I1")
-        I = np.empty((B, self.L, self.D))
-        sv = np.zeros((B, self.max_orders, self.L, self.D)) if save_orders else None
+        I = np.empty((B, self.L, self.D)) if fetch_field else None
         n = np.zeros(B, dtype=np.int32)
         st = np.zeros(B, dtype=np.int32)
-        check(lib().sosrt_solve(self._h, B, _ptr(tau), _ptr(Pa), _ptr(Pr), float(tol), _ptr(I1a), _ptr(I), _ptr(sv),
-                                _ptr(n), _ptr(st)))
+        sv = None
+        if save_orders:
+            # The per-order history has n entries (spec:304-305,458), n known only afterwards: a first pass without
+            # it (the field stays on the device) gives n, the second stores exactly max(n) orders per column --
+            # not max_orders of them (1.6 GB per column at the reference's shipped size with a 256-order budget).
+            check(lib().sosrt_solve(self._h, B, _ptr(tau), _ptr(Pa), _ptr(Pr), float(tol), _ptr(I1a), None, None, _ptr(n), _ptr(st)))
+            slots = int(max(1, n.max()))
+            check(lib().sosrt_set_saved_orders(self._h, slots))
+            sv = np.zeros((B, slots, self.L, self.D))
+        try:
+            check(lib().sosrt_solve(self._h, B, _ptr(tau), _ptr(Pa), _ptr(Pr), float(tol), _ptr(I1a), _ptr(I), _ptr(sv),
+                                    _ptr(n), _ptr(st)))
+        finally:
+            if save_orders:
+                check(lib().sosrt_set_saved_orders(self._h, self.max_orders))
         return SolveResult(I=I, n=n, status=st, I_saved=sv)
 
     def solve_device(self, d_tau: int, d_P0_atm: int, d_P0_aer: int, d_I_out: int, tol=1e-4, d_I1: int = 0,
@@ -182,6 +195,56 @@ class Solver:
         fu = np.empty((B, self.L))
         check(lib().sosrt_fluxes(self._h, B, _ptr(tau), _ptr(I), 0 if beam_norm == "crit" else 1, _ptr(fd), _ptr(fu)))
         return fd, fu
+
+    def epilogue(self, z_profile=None, beam_norm="crit", want=("flux_down", "flux_up", "diffusivity", "heating_rate", "net_toa")):
+        """Fluxes, diffusivity, heating rate and TOA net flux of the field the last `solve` left on the device
+        (graphe:10,74-91,157-158, crit:377-382); only these [B, L] / [B] arrays cross PCIe."""
+        B = self.B
+        want = set(want)
+        if z_profile is None:
+            want.discard("heating_rate")
+        z = None if z_profile is None else _f64(z_profile, (self.L,), "z_profile")
+        arr = {k: (np.empty(B) if k == "net_toa" else np.empty((B, self.L))) if k in want else None
+               for k in ("flux_down", "flux_up", "diffusivity", "heating_rate", "net_toa")}
+        check(lib().sosrt_epilogue(self._h, B, 0 if beam_norm == "crit" else 1, _ptr(z), _ptr(arr["flux_down"]),
+                                   _ptr(arr["flux_up"]), _ptr(arr["diffusivity"]), _ptr(arr["heating_rate"]),
+                                   _ptr(arr["net_toa"])))
+        return {k: v for k, v in arr.items() if v is not None}
+
+    def epilogue_device(self, d_tau: int, d_I: int, d_z: int = 0, beam_norm="crit", d_flux_down: int = 0, d_flux_up: int = 0,
+                        d_diffusivity: int = 0, d_heating_rate: int = 0, d_net_toa: int = 0):
+        """Same on caller-owned device buffers (addresses), enqueued on the handle's stream."""
+        vp = lambda x: ctypes.c_void_p(x) if x else None
+        check(lib().sosrt_epilogue_dev(self._h, self.B, vp(d_tau), vp(d_I), 0 if beam_norm == "crit" else 1, vp(d_z),
+                                       vp(d_flux_down), vp(d_flux_up), vp(d_diffusivity), vp(d_heating_rate), vp(d_net_toa)))
+
+    # ---- phase functions on the device (phase:68-292) ----------------------------
+    _KINDS = {"iso": _lib.PHASE_ISO, "rayleigh": _lib.PHASE_RAYLEIGH, "hg": _lib.PHASE_HG, "table": _lib.PHASE_TABLE}
+
+    def set_phase_table(self, tab_mu, tab_p):
+        tm = np.ascontiguousarray(tab_mu, dtype=np.float64)
+        tp = _f64(tab_p, tm.shape, "tab_p")
+        check(lib().sosrt_phase_table(self._h, _ptr(tm), _ptr(tp), int(tm.size)))
+
+    def phase_p0(self, kind, mu0, g=0.0):
+        """P0(mu, mu0[b]) for an array of mu0 -> [len(mu0), 2N]."""
+        m = np.ascontiguousarray(np.atleast_1d(mu0), dtype=np.float64)
+        out = np.empty((m.size, self.D))
+        step = max(1, self.max_batch)
+        for i in range(0, m.size, step):
+            mm = np.ascontiguousarray(m[i:i + step])
+            oo = np.empty((mm.size, self.D))
+            check(lib().sosrt_phase_p0(self._h, int(mm.size), self._KINDS[kind], float(g), _ptr(mm), _ptr(oo)))
+            out[i:i + step] = oo
+        return out
+
+    def phase_p0_device(self, kind, d_mu0: int, d_P0_out: int, B: int, g=0.0):
+        check(lib().sosrt_phase_p0_dev(self._h, int(B), self._KINDS[kind], float(g), ctypes.c_void_p(d_mu0), ctypes.c_void_p(d_P0_out)))
+
+    def phase_matrix(self, kind, g=0.0):
+        out = np.empty((self.D, self.D))
+        check(lib().sosrt_phase_matrix(self._h, self._KINDS[kind], float(g), _ptr(out)))
+        return out
 
     # ---- helper level ----------------------------------------------------------
     def limit_mu_down(self, rows, idx):

@@ -68,10 +68,11 @@ def _quiet():
 def _load_phase_builders():
     src = open(os.path.join(REF, "SOS_Aer_phase_func.py")).read()
     tree = ast.parse(src)
-    wanted = {"isotropic", "rayleigh", "henyey_greenstein"}
+    wanted = {"isotropic", "rayleigh", "henyey_greenstein", "fwc", "interpolate_fwc_phase"}
     body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
     mod = ast.Module(body=body, type_ignores=[])
-    ns = {"np": np, "tqdm": lambda it, **kw: it}
+    import SOS_Aer_fwc_data as R_fwc      # two literal arrays (fwc:3,173), pure data
+    ns = {"np": np, "tqdm": lambda it, **kw: it, "mu_fwc": R_fwc.mu_fwc, "phase_func_FWC": R_fwc.phase_func_FWC}
     exec(compile(mod, "<reference phase builders>", "exec"), ns)
     return ns
 
@@ -86,7 +87,28 @@ def ref_phase(name, N, mu, mu0, g=0.0):
         return _PB["rayleigh"](N, mu, mu0)
     if name == "hg":
         return _PB["henyey_greenstein"](N, mu, mu0, g)
+    if name == "fwc":
+        return _PB["fwc"](N, mu, mu0)
     raise ValueError(name)
+
+
+def _ref_P0_only(name, N, mu, mu0, g):
+    """P0 of a reference builder without its O(D^2 25) P(mu, mu') loop: the builder's statements up to and
+    including `P0 = P0/np.trapz(P0, mu) *2` are executed, the rest is dropped (run-time AST cut)."""
+    fn = {"rayleigh": "rayleigh", "hg": "henyey_greenstein", "fwc": "fwc"}[name]
+    src = open(os.path.join(REF, "SOS_Aer_phase_func.py")).read()
+    tree = ast.parse(src)
+    f = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fn][0]
+    cut = None
+    for i, st in enumerate(f.body):
+        if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name) and st.targets[0].id == "P0" and i > 3:
+            cut = i
+    assert cut is not None
+    f.body = f.body[:cut + 1] + [ast.Return(value=ast.Name(id="P0", ctx=ast.Load()))]
+    mod = ast.fix_missing_locations(ast.Module(body=[f], type_ignores=[]))
+    ns = dict(_PB)
+    exec(compile(mod, "<reference %s, P0 part>" % fn, "exec"), ns)
+    return ns[fn](N, mu, mu0, g) if name == "hg" else ns[fn](N, mu, mu0)
 
 
 def make_mu(N):
@@ -341,7 +363,33 @@ def g5():
             out["hg07_P0"], out["hg07_P"] = ref_phase("hg", N, mu, mu0, 0.7)
             out["hg03_P0"], out["hg03_P"] = ref_phase("hg", N, mu, mu0, 0.3)
             out["iso_P0"], out["iso_P"] = ref_phase("iso", N, mu, mu0)
+            out["fwc_P0"], out["fwc_P"] = ref_phase("fwc", N, mu, mu0)
             np.savez_compressed(os.path.join(OUT, "g5_phase_N%d_mu0_%g.npz" % (N, mu0)), **out)
+    # the BASELINE angular resolution: P0 for several mu0 of a sweep; P as digests (the matrices are 0.5 MB each)
+    N = 128
+    mu = make_mu(N)
+    out = {"mu": mu, "N": N, "mu0": np.array([0.2, 0.5, 0.8125, 1.0])}
+    for tag, name, g in (("ray", "rayleigh", 0.0), ("hg07", "hg", 0.7), ("fwc", "fwc", 0.0)):
+        P0s = []
+        for mu0 in out["mu0"]:
+            if name == "fwc" and mu0 != 0.5:
+                # the builder's P(mu, mu') loop dominates its cost and does not depend on mu0: P0 only
+                P0s.append(_ref_P0_only(name, N, mu, float(mu0), g))
+                continue
+            P0, P = ref_phase(name, N, mu, float(mu0), g)
+            P0s.append(P0)
+            if mu0 == 0.5:
+                out[tag + "_P_rows"] = P[[0, 1, N - 2, N - 1, N, N + 1, 2 * N - 2, 2 * N - 1]]
+                out[tag + "_P_colsum"] = P.sum(axis=0)
+                out[tag + "_P_diag"] = np.diag(P).copy()
+                out[tag + "_P_anti"] = np.diag(P[:, ::-1]).copy()
+        if name != "fwc":
+            pass
+        out[tag + "_P0"] = np.stack(P0s)
+    np.savez_compressed(os.path.join(OUT, "g5_phase_N128.npz"), **out)
+    # the tabulated fair-weather-cumulus phase function (fwc:3,173): data
+    import SOS_Aer_fwc_data as R_fwc
+    np.savez_compressed(os.path.join(OUT, "g5_fwc_table.npz"), mu_fwc=R_fwc.mu_fwc, phase_func_FWC=R_fwc.phase_func_FWC)
     # tau_profile
     import SOS_Aer_tau_profile as R_tp
     import matplotlib.pyplot as plt
@@ -359,9 +407,120 @@ def g5():
     print("g5 phase + tau_profile fixtures written")
 
 
+# --------------------------------------------------------------------------
+# G7: what the callers consume -- fluxes, diffusivity, heating rate (SOS_Aer_graphe.py:10,41,74-91,157-158),
+# TOA net flux, radiative forcing and critical albedo (SOS_Aer_critical_albedo.py:20-410)
+# --------------------------------------------------------------------------
+def _graphe_functions():
+    """The arithmetic of the reference's plot functions: each function's statements up to (not including) its
+    first `plt.` call are executed and its locals returned (run-time AST cut; nothing is stored)."""
+    src = open(os.path.join(REF, "SOS_Aer_graphe.py")).read()
+    tree = ast.parse(src)
+    out = []
+    for f in tree.body:
+        if not isinstance(f, ast.FunctionDef):
+            continue
+        cut = len(f.body)
+        for i, st in enumerate(f.body):
+            if "plt." in ast.unparse(st) and not isinstance(st, ast.For):
+                cut = i
+                break
+        ret = ast.parse("return dict(locals())").body[0]
+        f.body = f.body[:cut] + [ret]
+        out.append(f)
+    mod = ast.fix_missing_locations(ast.Module(body=out, type_ignores=[]))
+    import matplotlib.pyplot as plt       # graphe_successive_dif plots inside its loop over the orders
+    ns = {"np": np, "plt": plt}
+    exec(compile(mod, "<reference graphe arithmetic>", "exec"), ns)
+    return ns
+
+
+def _crit_functions(tauStar_tot):
+    """SOS_Aer_radiative_forcing / SOS_Aer_critical_albedo: lines 1-410 of the reference file (its script body
+    is not run), with the module-global `tauStar_tot` the function relies on (crit:39 vs crit:486) injected.
+    A second copy of the forcing function returns its locals at the point of `return net_flux_toa`."""
+    lines = open(os.path.join(REF, "SOS_Aer_critical_albedo.py")).read().split("\n")
+    end = [i for i, l in enumerate(lines) if l.startswith("#                   MAIN SCRIPT")][0] - 1
+    src = "\n".join(lines[:end])
+    src = src.replace("from I1_In import", "from SOS_Aer_I1_In import")
+    src = re.sub(r"^from SOS_Aer_phase_func import .*$", "", src, flags=re.M)
+    src = re.sub(r"^from tqdm import .*$", "", src, flags=re.M)
+    ns = {"__name__": "ref_crit", "tauStar_tot": tauStar_tot}
+    exec(compile(src, "<reference critical_albedo, functions only>", "exec"), ns)
+    src2, nsub = re.subn(r"^        return net_flux_toa\s*$", "        return dict(locals())", src, flags=re.M)
+    assert nsub == 1
+    ns2 = {"__name__": "ref_crit_locals", "tauStar_tot": tauStar_tot}
+    exec(compile(src2, "<reference critical_albedo, locals>", "exec"), ns2)
+    return ns, ns2
+
+
+def g7():
+    G = _graphe_functions()
+    base = dict(z0=120, z_up=25, z_down=17, tauStar_atm=0.104, tauStar_aer=0.120, alb_atm=1.0, alb_aer=1.0)
+    cases = [
+        ("C1_iso", dict(base, mu0=0.5, nb_layers=50, nb_angles=32, grd_alb=0.15), ("iso", 0.0), ("iso", 0.0)),
+        ("L60_N64_ray_hg", dict(base, mu0=0.6, nb_layers=60, nb_angles=64, grd_alb=0.3, tauStar_aer=0.6, alb_aer=0.9),
+         ("rayleigh", 0.0), ("hg", 0.7)),
+        ("L40_N128_ray_hg", dict(base, mu0=0.35, nb_layers=40, nb_angles=128, grd_alb=0.05, tauStar_atm=0.124, alb_aer=0.97),
+         ("rayleigh", 0.0), ("hg", 0.7)),
+    ]
+    for name, p, atm, aer in cases:
+        out, loc = _column_case("specular", p, atm, aer, store="full+P")
+        L, N = p["nb_layers"], p["nb_angles"]
+        I, mu, tau, mu0 = loc["I"], loc["mu"], loc["tau"], p["mu0"]
+        z = np.linspace(p["z0"], 0, L)
+        F0 = np.pi / mu0
+        iu, idn = int(loc["idx_up"]), int(loc["idx_down"])
+        with _quiet():
+            r = G["graphe_diffusivity"](I, mu, z, L, "x")
+            out["diffusivity"] = r["dif"]
+            r = G["graphe_flux"](I, mu, z, L, N, tau, mu0, F0, p["grd_alb"], "x")
+            out["flux_net_F0"] = r["flux"]
+            r = G["graphe_flux_up_down"](I, mu, z, L, N, tau, mu0, F0, p["grd_alb"], "x")
+            out["flux_up_F0"], out["flux_down_F0"] = r["flux_up"], r["flux_down"]
+            r = G["graphe_heating_rate"](I, mu, z, L, N, iu, idn, F0, mu0, tau, p["grd_alb"], "x")
+            out["flux_up_4pi"], out["flux_down_4pi"] = r["flux_up"], r["flux_down"]
+            out["heating_rate"] = r["heating_rate"]
+            r = G["graphe_successive_dif"](loc["I_saved"], mu, z, L, N, "x")
+            out["diffusivity_last_order"] = r["dif"]
+        # the function-form column of crit (own copy of the column arithmetic) on the same inputs
+        tst = p["tauStar_atm"] + p["tauStar_aer"]
+        C, C2 = _crit_functions(tst)
+        args = (loc["dtau_aer"], p["tauStar_atm"], loc["dtau_atm"], loc["P_aer"], loc["P0_aer"], p["alb_aer"], loc["P_atm"],
+                loc["P0_atm"], p["alb_atm"], p["grd_alb"], F0, mu, mu0, N, tau, L, iu, idn)
+        with _quiet():
+            lc = C2["SOS_Aer_radiative_forcing"](0, *args)          # tauStar_aer == 0 -> the branch that returns the net flux
+            out["crit_net_flux_toa"] = np.float64(lc["net_flux_toa"])
+            out["crit_flux_up"], out["crit_flux_down"] = lc["flux_up"], lc["flux_down"]
+            out["crit_I_minus_spec_I_max"] = np.float64(np.max(np.abs(lc["I"] - I)))
+            out["crit_n"] = lc["n"]
+            out["crit_delta_F_coded"] = np.float64(C["SOS_Aer_radiative_forcing"](p["tauStar_aer"], *args))
+            if name == "C1_iso":
+                cargs = (p["tauStar_aer"], loc["dtau_aer"], p["tauStar_atm"], loc["dtau_atm"], loc["P_aer"], loc["P0_aer"],
+                         loc["P_atm"], loc["P0_atm"], p["alb_atm"], p["grd_alb"], F0, mu, mu0, N, tau, L, iu, idn)
+                out["crit_critical_albedo_coded"] = np.float64(C["SOS_Aer_critical_albedo"](*cargs))
+                # the net flux at the albedos a bisection with a working baseline would visit
+                for w in (0.5, 0.75, 0.875):
+                    a2 = list(args); a2[5] = w
+                    out["crit_net_flux_toa_alb%g" % w] = np.float64(C2["SOS_Aer_radiative_forcing"](0, *a2)["net_flux_toa"])
+        # the aerosol-free column on its own grid (the baseline a forcing needs; SURVEY 8f-3): spec exec
+        p0 = dict(p, tauStar_aer=0.0)
+        out0, loc0 = _column_case("specular", p0, atm, aer, store="digest")
+        C0, C02 = _crit_functions(p["tauStar_atm"])
+        a0 = (loc0["dtau_aer"], p["tauStar_atm"], loc0["dtau_atm"], loc0["P_aer"], loc0["P0_aer"], p["alb_aer"], loc0["P_atm"],
+              loc0["P0_atm"], p["alb_atm"], p["grd_alb"], F0, mu, mu0, N, loc0["tau"], L, iu, idn)
+        with _quiet():
+            out["crit_net_flux_toa_no_aerosol"] = np.float64(C02["SOS_Aer_radiative_forcing"](0, *a0)["net_flux_toa"])
+        out["n_no_aerosol"] = loc0["n"]
+        out.pop("I_saved")                      # the per-order fields are pinned by g3; here only the total is used
+        np.savez_compressed(os.path.join(OUT, "g7_epilogue_%s.npz" % name), **out)
+        print("g7", name, "n=%d net TOA flux %.12g  coded dF %g  |I_crit - I_spec| %.2e" % (
+            loc["n"], out["crit_net_flux_toa"], out["crit_delta_F_coded"], out["crit_I_minus_spec_I_max"]))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7")
     a = ap.parse_args()
     cwd = os.getcwd()
     import tempfile

@@ -26,6 +26,9 @@ def test_bench_single_gpu_line():
     assert d["roofline"]["bound"] in ("mfma", "hbm") and 0 < d["roofline"]["frac"] < 1
     assert {d["roofline"]["kernel"], d["roofline_other"]["kernel"]} == {"k_jn_gemm", "k_transport_ring"}
     assert d["config"]["not_converged"] == 0 and d["config"]["columns_per_gpu"] == 64
+    # the run checks itself: sampled columns against the oracle, outside the timed region
+    assert d["check"]["ok"] and d["check"]["max_rel_err_vs_oracle"] <= 1e-10 and d["check"]["orders_match"]
+    assert d["check"]["p0_max_rel_err_vs_oracle"] <= 1e-12
 
 
 def test_bench_two_ranks_share_the_gpu():
@@ -38,4 +41,21 @@ def test_bench_two_ranks_share_the_gpu():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["columns_per_gpu"] == 27 and "cpu_baseline" not in d
+    assert d["config"]["columns_per_gpu"] == [27, 27] and "cpu_baseline" not in d
+    assert len(d["config"]["orders_per_step_per_rank"]) == 2 and d["check"]["ok"]
+
+
+def test_bench_strong_scaling_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment starts the two ranks itself; --scaling strong deals ONE
+    sweep to them by expected work and gathers the whole fields to rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SOSRT_BENCH_BACKEND="gloo", SOSRT_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--scaling", "strong", "--steps", "2", "--warmup", "1",
+                        "--columns", "27"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert sorted(d["config"]["columns_per_gpu"]) == [13, 14]
+    per = d["config"]["orders_per_step_per_rank"]
+    assert max(per) / min(per) < 1.3                      # the deal balances the sum of orders
+    assert d["check"]["ok"] and d["check"]["gather_places_columns"]

@@ -244,3 +244,22 @@ def test_many_distinct_slab_coefficients_fall_back_to_two_passes():
         ok = (r.status[sl] == 0) & (rs.status == 0)
         assert np.array_equal(rs.n[ok], r.n[sl][ok])
         assert_close(rs.I[ok], r.I[sl][ok], 1e-12, "two-pass vs combined-matrix slab tiles")
+
+
+def test_sharded_solve_equals_single_rank_bit_for_bit():
+    """SOS_Aer_batch(devices=[0, 0]): two worker processes (gloo, sharing the one GPU of the test box) solve their
+    shards of a ragged sweep and gather; a column's result does not depend on the batch it was solved in."""
+    rng = np.random.default_rng(7)
+    B = 37
+    mu0 = rng.uniform(0.2, 1.0, B)
+    taer = rng.choice([0.02, 0.1, 0.35, 0.9], B)          # four optical-depth profiles -> four slab coefficient pairs
+    rho = rng.uniform(0.0, 0.8, B)
+    kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=40, nb_angles=64, max_orders=200)
+    one = SOS_Aer_batch(mu0, taer, rho, **kw)
+    two = SOS_Aer_batch(mu0, taer, rho, devices=[0, 0], **kw)
+    assert np.array_equal(one.n, two.n) and np.array_equal(one.status, two.status)
+    assert np.array_equal(one.tau, two.tau)
+    assert np.array_equal(one.I, two.I)                    # bit for bit
+    # and the same holds for a sub-batch solved on its own (different tilings of the contraction)
+    sub = SOS_Aer_batch(mu0[:5], taer[:5], rho[:5], **kw)
+    assert np.array_equal(sub.I, one.I[:5])

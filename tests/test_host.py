@@ -83,14 +83,19 @@ def test_argument_errors():
 
 
 def test_input_builders():
-    for path in golden("g5_phase_*.npz"):
+    for path in golden("g5_phase_N32_*.npz"):
         d = np.load(path)
         N, mu, mu0 = int(d["N"]), d["mu"], float(d["mu0"])
         assert np.array_equal(inputs.direction_grid(N), mu)
-        for nm, name, g in (("ray", "rayleigh", 0), ("hg07", "hg", 0.7), ("hg03", "hg", 0.3), ("iso", "iso", 0)):
+        for nm, name, g in (("ray", "rayleigh", 0), ("hg07", "hg", 0.7), ("hg03", "hg", 0.3), ("iso", "iso", 0), ("fwc", "fwc", 0)):
             P0, P = inputs.phase_function(name, N, mu, mu0, g)
-            assert_close(P0, d[nm + "_P0"], 1e-14, nm)
-            assert_close(P, d[nm + "_P"], 1e-14, nm)
+            assert_close(P0, d[nm + "_P0"], 1e-13, nm)
+            assert_close(P, d[nm + "_P"], 1e-13, nm)
+    d = np.load(golden("g5_phase_N128.npz")[0])
+    for k, m0 in enumerate(d["mu0"]):          # the BASELINE angular resolution
+        for nm, name, g in (("ray", "rayleigh", 0), ("hg07", "hg", 0.7), ("fwc", "fwc", 0)):
+            assert_close(inputs.phase_function(name, 128, d["mu"], float(m0), g)[0] if k else
+                         inputs._azimuth_averaged(inputs._scalar_phase(name, g)[0], d["mu"], float(m0))[0], d[nm + "_P0"][k], 1e-13, nm)
     with pytest.raises(ValueError):
         inputs.phase_function("nope", 8, inputs.direction_grid(8), 0.5)
     d = np.load(golden("g5_tau_profile.npz")[0])

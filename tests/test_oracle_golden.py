@@ -73,17 +73,69 @@ def test_c2_digest():
 
 
 def test_inputs():
-    for path in golden("g5_phase_*.npz"):
+    tab = np.load(golden("g5_fwc_table.npz")[0])
+    mt, pt = tab["mu_fwc"], tab["phase_func_FWC"]
+    for path in golden("g5_phase_N32_*.npz"):
         d = np.load(path)
         N, mu, mu0 = int(d["N"]), d["mu"], float(d["mu0"])
         for nm, (P0, P) in (("ray", O.phase_rayleigh(N, mu, mu0)), ("hg07", O.phase_hg(N, mu, mu0, 0.7)),
-                            ("hg03", O.phase_hg(N, mu, mu0, 0.3)), ("iso", O.phase_isotropic(N, mu))):
-            assert_close(P0, d[nm + "_P0"], 1e-14, nm)
-            assert_close(P, d[nm + "_P"], 1e-14, nm)
+                            ("hg03", O.phase_hg(N, mu, mu0, 0.3)), ("iso", O.phase_isotropic(N, mu)),
+                            ("fwc", O.phase_table(N, mu, mu0, mt, pt))):
+            assert_close(P0, d[nm + "_P0"], 1e-13, nm)
+            assert_close(P, d[nm + "_P"], 1e-13, nm)
+    # the BASELINE angular resolution: P0 for four mu0, P through digests
+    d = np.load(golden("g5_phase_N128.npz")[0])
+    N, mu = int(d["N"]), d["mu"]
+    rows = [0, 1, N - 2, N - 1, N, N + 1, 2 * N - 2, 2 * N - 1]
+    for nm, fn in (("ray", lambda m0: O.phase_rayleigh(N, mu, m0)), ("hg07", lambda m0: O.phase_hg(N, mu, m0, 0.7)),
+                   ("fwc", lambda m0: O.phase_table(N, mu, m0, mt, pt))):
+        for k, m0 in enumerate(d["mu0"]):
+            P0, P = fn(float(m0))
+            assert_close(P0, d[nm + "_P0"][k], 1e-13, "%s P0 mu0=%g" % (nm, m0))
+            if m0 == 0.5:
+                assert_close(P[rows], d[nm + "_P_rows"], 1e-13, nm)
+                assert_close(P.sum(axis=0), d[nm + "_P_colsum"], 1e-13, nm)
+                assert_close(np.diag(P), d[nm + "_P_diag"], 1e-13, nm)
+                assert_close(np.diag(P[:, ::-1]), d[nm + "_P_anti"], 1e-13, nm)
     d = np.load(golden("g5_tau_profile.npz")[0])
     for i in range(int(d["n"])):
         ta, tr, z0, zu, zd, L = d["p%d" % i]
         assert np.array_equal(O.tau_profile(ta, tr, z0, zu, zd, int(L)), d["tau%d" % i])
+
+
+@pytest.mark.parametrize("path", golden("g7_*.npz"), ids=lambda p: p.split("/")[-1][12:-4])
+def test_epilogue(path):
+    """Fluxes, diffusivity, heating rate (graphe), TOA net flux, forcing and critical albedo (crit)."""
+    d, c = column_case(path)
+    I, mu, tau, N, L, mu0, rho = d["I"], c["mu"], c["tau"], c["N"], c["L"], c["mu0"], c["grd_alb"]
+    z = np.linspace(c["z0"], 0, L)
+    assert_close(O.diffusivity(I, mu), d["diffusivity"], 1e-14, "diffusivity")
+    assert_close(O.net_flux(I, mu, tau, N, mu0, rho), d["flux_net_F0"], 1e-13, "net flux")
+    fd, fu = O.fluxes(I, mu, tau, N, mu0, rho, beam_norm="graphe")
+    assert np.array_equal(fd, d["flux_down_F0"]) and np.array_equal(fu, d["flux_up_F0"])
+    fd, fu = O.fluxes(I, mu, tau, N, mu0, rho, beam_norm="crit")
+    assert np.array_equal(fd, d["flux_down_4pi"]) and np.array_equal(fu, d["flux_up_4pi"])
+    assert np.array_equal(fd, d["crit_flux_down"]) and np.array_equal(fu, d["crit_flux_up"])
+    assert np.array_equal(O.heating_rate(I, mu, tau, N, mu0, rho, z, c["idx_up"], c["idx_down"]), d["heating_rate"])
+    assert O.toa_net_flux(I, mu, tau, N, mu0, rho) == float(d["crit_net_flux_toa"])
+    # the oracle's own column gives the same net flux to rounding, the coded forcing is exactly zero
+    col = oracle_column(O, c)
+    s = O.solve_column(col, literal=False)
+    assert s.n == int(d["crit_n"])
+    assert O.toa_net_flux(s.I, mu, tau, N, mu0, rho) == pytest.approx(float(d["crit_net_flux_toa"]), rel=1e-12)
+    if L * N <= 2000:
+        assert O.radiative_forcing(col) == float(d["crit_delta_F_coded"]) == 0.0
+        assert O.critical_albedo(lambda w: 0.0) == float(d["crit_critical_albedo_coded"]) == 0.5
+        for w in (0.5, 0.75, 0.875):
+            cw = oracle_column(O, dict(c, alb_aer=w))
+            f = O.toa_net_flux(O.solve_column(cw, literal=False).I, mu, tau, N, mu0, rho)
+            assert f == pytest.approx(float(d["crit_net_flux_toa_alb%g" % w]), rel=1e-12)
+    base = oracle_column(O, dict(c, tauStar_aer=0.0))
+    sb = O.solve_column(base, literal=False)
+    assert sb.n == int(d["n_no_aerosol"])
+    assert O.toa_net_flux(sb.I, base.mu, base.tau, N, mu0, rho) == pytest.approx(float(d["crit_net_flux_toa_no_aerosol"]), rel=1e-12)
+    assert O.radiative_forcing(col, baseline=base) == pytest.approx(
+        float(d["crit_net_flux_toa"]) - float(d["crit_net_flux_toa_no_aerosol"]), rel=1e-10)
 
 
 def test_fp32_contraction_misses_the_parity_bar():

@@ -16,7 +16,8 @@ s.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 s.set_grid(w["mu"]); s.set_phase(w["P_atm"], w["P_aer"])
 s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
               w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
-d_tau = torch.from_numpy(w["tau"]).to(dev); d_P0a = torch.from_numpy(w["P0a"]).to(dev); d_P0r = torch.from_numpy(w["P0r"]).to(dev)
+P0a, P0r = bench.host_p0(w)
+d_tau = torch.from_numpy(w["tau"]).to(dev); d_P0a = torch.from_numpy(P0a).to(dev); d_P0r = torch.from_numpy(P0r).to(dev)
 d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev); d_n = torch.zeros(B, dtype=torch.int32, device=dev)
 st = torch.zeros((B, 2, 8), dtype=torch.int64, device=dev)
 for it in range(int(os.environ.get("STAMP_ITERS", "2"))):
