@@ -59,6 +59,16 @@ struct sosrt_handle {
     int saved_slots = 0;                 // orders per column in I_saved_out (sosrt_set_saved_orders; default max_orders)
     bool gpu = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // Column groups of the order loop: a large batch is solved as two halves, the second on an internal stream, so
+    // that the MFMA-bound contraction of one half overlaps the HBM-bound transport of the other (SOSRT_GROUPS)
+    static constexpr int kMaxGroups = 2;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int ngroups = 1, want_groups = 1, split_min = 256;
+    double stagger = 1.0;                // a group starts when the previous one is down to this fraction of live columns (SOSRT_STAGGER; 1: together)
+    int gb[kMaxGroups + 1] = {0, 0, 0};                    // column range of group g: [gb[g], gb[g+1])
+    int main_off[kMaxGroups + 1] = {0, 0, 0};              // its plain rows in d_mainrows
+    int slab_off[kMaxGroups + 1] = {0, 0, 0};              // its slab rows in d_slabrows (tile-aligned when grouped by coefficient pair)
     Plan plan;
     bool have_grid = false, have_phase = false, have_aer = false, have_cols = false;
     int B = 0, geom = 0, surface = 0;
@@ -104,12 +114,12 @@ struct sosrt_handle {
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
     bool fast_ok = false;
     double* d_ratio = nullptr;
-    int* h_pub = nullptr;                // pinned [2][2]: {live count, tag} published from the device
+    int* h_pub = nullptr;                // pinned [groups][2 slots][4]: {live count, tag, needs k_smallmu, -} published from the device
     bool need_small = true;              // some column keeps a k_smallmu value (known from the second order on)
     int pub_seq = 0;                     // tags are unique across solves
     int last_max_orders = 0;
     long long last_sum_orders = 0;
-    Prof prof;
+    Prof prof[kMaxGroups];               // per column group (= per stream)
 };
 
 namespace {
@@ -138,29 +148,30 @@ bool prof_room(Prof& p) {
     }
     return true;
 }
-void prof_begin(sosrt_handle* h, int kind) {
-    Prof& p = h->prof;
+hipStream_t group_stream(sosrt_handle* h, int grp) { return grp == 0 ? h->stream : h->stream2; }
+void prof_begin(sosrt_handle* h, int kind, int grp = 0) {
+    Prof& p = h->prof[grp];
     p.open = -1;
     if (!p.on || !prof_room(p)) return;
     if (p.adjacent >= 0) {
         p.open = p.adjacent;
     } else {
         p.open = (int)p.used++;
-        hipEventRecord(p.ev[p.open], h->stream);
+        hipEventRecord(p.ev[p.open], group_stream(h, grp));
     }
 }
-void prof_end(sosrt_handle* h, int kind) {
-    Prof& p = h->prof;
+void prof_end(sosrt_handle* h, int kind, int grp = 0) {
+    Prof& p = h->prof[grp];
     if (!p.on || p.open < 0) return;
     const int e = (int)p.used++;
-    hipEventRecord(p.ev[e], h->stream);
+    hipEventRecord(p.ev[e], group_stream(h, grp));
     p.kind[p.nint] = kind; p.first[p.nint] = p.open; p.last[p.nint] = e;
     ++p.nint;
     p.adjacent = e;
     p.open = -1;
 }
 // work enqueued outside a bracket: the next bracket needs its own opening event
-void prof_break(sosrt_handle* h) { h->prof.adjacent = -1; }
+void prof_break(sosrt_handle* h) { for (auto& p : h->prof) p.adjacent = -1; }
 
 int need_gpu(sosrt_handle* h) {
     if (!h) return fail(SOSRT_E_INVALID, "null handle");
@@ -170,8 +181,8 @@ int need_gpu(sosrt_handle* h) {
 
 // Live columns after the order whose tag is `tag`, as published by the source-function launch of the
 // next order (publish_live in kernels.hpp).  Spins on pinned memory; negative = error code.
-int wait_published(sosrt_handle* h, int tag) {
-    volatile int* slot = h->h_pub + 4 * (tag & 1);
+int wait_published(sosrt_handle* h, int grp, int tag) {
+    volatile int* slot = h->h_pub + 8 * grp + 4 * (tag & 1);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 1;; ++it) {
         if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) == tag) {
@@ -179,7 +190,7 @@ int wait_published(sosrt_handle* h, int tag) {
             return slot[0];
         }
         if ((it & 0x3fff) == 0) {
-            const hipError_t q = hipStreamQuery(h->stream);
+            const hipError_t q = hipStreamQuery(group_stream(h, grp));
             if (q != hipSuccess && q != hipErrorNotReady) return fail(SOSRT_E_HIP, "order loop: %s", hipGetErrorString(q));
             if (q == hipSuccess && __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != tag)
                 return fail(SOSRT_E_HIP, "order loop: the stream drained without publishing order tag %d", tag);
@@ -219,32 +230,51 @@ ColScalars scalars_of(sosrt_handle* h) {
     return sc;
 }
 
-// Jn for every row of the batch in one launch: plain rows against W_atm, slab rows against W_atm and W_aer
-void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0) {
+// Jn for every row of a column group (grp < 0: the whole batch) in one launch: plain rows against W_atm, slab rows
+// against the combined matrix of their coefficient pair (or W_atm and W_aer in two passes)
+void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0,
+                int grp = -1) {
+    const int g0 = grp < 0 ? 0 : grp, g1 = grp < 0 ? h->ngroups : grp + 1;
+    const int pg = grp < 0 ? 0 : grp;
+    hipStream_t s = group_stream(h, pg);
     GemmArgs ga;
     ga.A = In_1; ga.Wa = h->d_Wa; ga.Wr = h->d_Wr; ga.ca = h->d_rca; ga.cr = h->d_rcr;
-    ga.rows_main = h->nslab > 0 ? h->d_mainrows : nullptr;
-    ga.n_main = h->nslab > 0 ? h->nmain : h->B * h->L;
-    ga.rows_slab = h->d_slabrows; ga.n_slab = h->nslab;
+    if (h->nslab > 0) {
+        ga.rows_main = h->d_mainrows + h->main_off[g0];
+        ga.n_main = h->main_off[g1] - h->main_off[g0];
+    } else {                                           // no slab rows: the identity list, offset by the group's first row
+        ga.rows_main = nullptr;
+        ga.n_main = (h->gb[g1] - h->gb[g0]) * h->L;
+        ga.A = In_1 + (size_t)h->gb[g0] * h->L * h->D;
+        Jn += (size_t)h->gb[g0] * h->L * h->D;
+        ga.ca = h->d_rca + (size_t)h->gb[g0] * h->L;
+        ga.cr = h->d_rcr + (size_t)h->gb[g0] * h->L;
+        if (active) active += h->gb[g0];
+    }
+    ga.rows_slab = h->d_slabrows + h->slab_off[g0]; ga.n_slab = h->slab_off[g1] - h->slab_off[g0];
     ga.D = h->g.D; ga.Dp = h->g.Dp; ga.Wld = h->g.Wld; ga.L = h->L; ga.C = Jn; ga.active = active;
-    if (pub_tag) { ga.nactive = h->d_nactive; ga.host_pub = h->h_pub; ga.tag = pub_tag; }
+    if (pub_tag) {
+        ga.nactive = h->d_nactive + pg; ga.need_small = h->d_nactive + sosrt_handle::kMaxGroups;
+        ga.host_pub = h->h_pub + 8 * pg; ga.tag = pub_tag;
+    }
     if (h->mix_groups > 0) {
         if (h->mix_dirty) {
             prof_break(h);
-            launch_wmix(h->stream, (size_t)h->g.Dp * h->g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
+            launch_wmix(s, (size_t)h->g.Dp * h->g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
             h->mix_dirty = false;
         }
-        ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; ga.slab_tile_group = h->d_slabtilegroup;
+        ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; ga.slab_tile_group = h->d_slabtilegroup + h->slab_off[g0] / 32;
     }
-    prof_begin(h, SOSRT_K_GEMM);
-    if (tail_cols > 0 && active) {
-        ga.B = h->B; ga.max_main = h->max_main; ga.max_slab = h->max_slab;
+    prof_begin(h, SOSRT_K_GEMM, pg);
+    if (tail_cols > 0 && active && h->nslab >= 0) {
+        ga.col0 = h->nslab > 0 ? h->gb[g0] : 0; ga.B = h->gb[g1] - h->gb[g0];
+        ga.max_main = h->max_main; ga.max_slab = h->max_slab;
         ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
-        launch_gemm_tail(h->stream, ga, tail_cols, tail_cols <= h->gemm_small_cols);
+        launch_gemm_tail(s, ga, tail_cols, tail_cols <= h->gemm_small_cols);
     } else {
-        launch_gemm(h->stream, ga);
+        launch_gemm(s, ga);
     }
-    prof_end(h, SOSRT_K_GEMM);
+    prof_end(h, SOSRT_K_GEMM, pg);
 }
 
 }  // namespace
@@ -273,6 +303,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
         h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : 1);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
+    if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
+    if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
+    if (const char* ev = getenv("SOSRT_STAGGER")) h->stagger = atof(ev);
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_LOADERS")) g_ring_loaders = atoi(ev);
 #ifdef SOSRT_RING_DEBUG   // diagnostic builds only: the switches make the ring kernel skip work, its results are wrong
@@ -288,6 +321,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             HIPCHK(hipSetDevice(device));
             HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
             h->stream = h->own_stream;
+            HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             const size_t mb = max_batch, fe = field_elems(h);
             if ((e = dalloc(&h->d_mu, g.D))) return e;
             if ((e = dalloc(&h->d_Wa, (size_t)g.Dp * g.Wld))) return e;
@@ -305,8 +341,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_desc, mb))) return e;
             if ((e = dalloc(&h->d_rca, mb * L))) return e;
             if ((e = dalloc(&h->d_rcr, mb * L))) return e;
-            if ((e = dalloc(&h->d_slabrows, mb * L + 32 * (size_t)sosrt_handle::kMaxMixGroups))) return e;   // + padding per group
-            if ((e = dalloc(&h->d_slabtilegroup, mb * L / 32 + sosrt_handle::kMaxMixGroups + 1))) return e;
+            if ((e = dalloc(&h->d_slabrows, mb * L + 32 * (size_t)sosrt_handle::kMaxMixGroups * sosrt_handle::kMaxGroups))) return e;   // + padding
+            if ((e = dalloc(&h->d_slabtilegroup, mb * L / 32 + sosrt_handle::kMaxMixGroups * sosrt_handle::kMaxGroups + 1))) return e;
             if ((e = dalloc(&h->d_mainrows, mb * L))) return e;
             if ((e = dalloc(&h->d_tau, mb * L))) return e;
             if ((e = dalloc(&h->d_P0a, mb * g.D))) return e;
@@ -319,7 +355,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_active, mb))) return e;
             if ((e = dalloc(&h->d_norders, mb))) return e;
             if ((e = dalloc(&h->d_status, mb))) return e;
-            if ((e = dalloc(&h->d_nactive, 2))) return e;          // live columns; any column needs k_smallmu
+            if ((e = dalloc(&h->d_nactive, sosrt_handle::kMaxGroups + 1))) return e;   // live columns per group; any column needs k_smallmu
             if ((e = dalloc(&h->d_redo, mb))) return e;
             if ((e = dalloc(&h->d_erep, mb))) return e;
             if ((e = dalloc(&h->d_mixgroup, mb))) return e;
@@ -327,8 +363,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_mixcr, sosrt_handle::kMaxMixGroups))) return e;
             if ((e = dalloc(&h->d_tauhash, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
-            HIPCHK(hipHostMalloc((void**)&h->h_pub, 8 * sizeof(int), hipHostMallocCoherent));
-            memset(h->h_pub, 0, 8 * sizeof(int));
+            HIPCHK(hipHostMalloc((void**)&h->h_pub, 8 * sosrt_handle::kMaxGroups * sizeof(int), hipHostMallocCoherent));
+            memset(h->h_pub, 0, 8 * sosrt_handle::kMaxGroups * sizeof(int));
 
             HIPCHK(hipMemset(h->d_Wa, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
             HIPCHK(hipMemset(h->d_Wr, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
@@ -359,7 +395,11 @@ int sosrt_destroy(sosrt_t* h) {
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
 
-        for (auto& e : h->prof.ev) hipEventDestroy(e);
+        for (auto& p : h->prof)
+            for (auto& e : p.ev) hipEventDestroy(e);
+        if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+        if (h->ev_fork) hipEventDestroy(h->ev_fork);
+        if (h->ev_join) hipEventDestroy(h->ev_join);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
     delete h;
@@ -471,12 +511,23 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
             if (idx_up[b] < 1 || idx_down[b] < idx_up[b] || idx_down[b] > h->L - 2)
                 return fail(SOSRT_E_INVALID, "column %d: need 1 <= idx_up <= idx_down <= nb_layers-2 (got %d, %d)", b,
                             idx_up[b], idx_down[b]);
-            for (int t = 0; t < h->L; ++t) (t >= idx_up[b] && t <= idx_down[b] ? slab : plain).push_back(b * h->L + t);
         }
     } else if (geometry == SOSRT_GEOM_SINGLE_SLAB) {
         surface = SOSRT_SURFACE_NONE;
     } else {
         return fail(SOSRT_E_INVALID, "unknown geometry %d", geometry);
+    }
+    // column groups of the order loop: two contiguous halves for a large batch
+    h->ngroups = (h->want_groups >= 2 && B >= h->split_min && B >= 2) ? 2 : 1;
+    h->gb[0] = 0; h->gb[1] = h->ngroups == 2 ? B / 2 : B; h->gb[2] = B;
+    for (int k = 0; k <= sosrt_handle::kMaxGroups; ++k) { h->main_off[k] = 0; h->slab_off[k] = 0; }
+    if (geometry == SOSRT_GEOM_THREE_ZONE) {
+        for (int k = 0; k < h->ngroups; ++k) {
+            for (int b = h->gb[k]; b < h->gb[k + 1]; ++b)
+                for (int t = 0; t < h->L; ++t) (t >= idx_up[b] && t <= idx_down[b] ? slab : plain).push_back(b * h->L + t);
+            h->main_off[k + 1] = (int)plain.size();
+            h->slab_off[k + 1] = (int)slab.size();
+        }
     }
     for (int b = 0; b < B; ++b) {
         if (!(mu0[b] > 0)) return fail(SOSRT_E_INVALID, "column %d: mu0 must be > 0", b);
@@ -541,14 +592,18 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
                 HIPCHK(hipMemcpy(h->d_mixcr, gcr.data(), gcr.size() * sizeof(double), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(h->d_mixgroup, gid.data(), B * sizeof(int), hipMemcpyHostToDevice));
                 h->mix_groups = (int)gca.size();
-                // slab rows of the dense contraction listed group by group, every group padded to whole 32-row tiles
+                // slab rows of the dense contraction listed, per column group of the order loop, coefficient pair by
+                // coefficient pair, every pair padded to whole 32-row tiles
                 std::vector<int> grouped, tilegroup;
-                for (int k = 0; k < h->mix_groups; ++k) {
-                    for (int b = 0; b < B; ++b)
-                        if (gid[b] == k)
-                            for (int t = idx_up[b]; t <= idx_down[b]; ++t) grouped.push_back(b * h->L + t);
-                    while (grouped.size() % 32) grouped.push_back(-1);
-                    while (tilegroup.size() < grouped.size() / 32) tilegroup.push_back(k);
+                for (int cg = 0; cg < h->ngroups; ++cg) {
+                    for (int k = 0; k < h->mix_groups; ++k) {
+                        for (int b = h->gb[cg]; b < h->gb[cg + 1]; ++b)
+                            if (gid[b] == k)
+                                for (int t = idx_up[b]; t <= idx_down[b]; ++t) grouped.push_back(b * h->L + t);
+                        while (grouped.size() % 32) grouped.push_back(-1);
+                        while (tilegroup.size() < grouped.size() / 32) tilegroup.push_back(k);
+                    }
+                    h->slab_off[cg + 1] = (int)grouped.size();
                 }
                 HIPCHK(hipMemcpy(h->d_slabrows, grouped.data(), grouped.size() * sizeof(int), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(h->d_slabtilegroup, tilegroup.data(), tilegroup.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -669,16 +724,19 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     if (!d_tau || !d_I_out) return fail(SOSRT_E_INVALID, "null argument");
     if (!d_I1_in && !d_P0_atm) return fail(SOSRT_E_INVALID, "P0_atm is required unless I1 is supplied");
     if (!d_I1_in && h->geom == SOSRT_GEOM_THREE_ZONE && !d_P0_aer) return fail(SOSRT_E_INVALID, "three-zone geometry needs P0_aer");
+    if (h->max_orders >= 65536) return fail(SOSRT_E_INVALID, "max_orders must be < 65536");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const Grid& g = h->g;
     const size_t LD = (size_t)h->L * h->D;
     const size_t saved_stride = (size_t)h->saved_slots * LD;
-    Conv cv = make_conv(h, tol);
+    const int NG = h->ngroups;
 
     prof_break(h);
-    HIPCHK(hipMemsetAsync(h->d_nactive, 0, 2 * sizeof(int), s));
-    launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr, h->d_nactive + 1);
+    // per-sweep setup on the caller's stream: zone tables, shared attenuation tables, combined slab matrices
+    HIPCHK(hipMemsetAsync(h->d_nactive, 0, (sosrt_handle::kMaxGroups + 1) * sizeof(int), s));
+    launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr,
+                   h->d_nactive + sosrt_handle::kMaxGroups);
     h->need_small = true;
     const bool fast = h->transport_mode >= 1 && h->fast_ok;
     const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
@@ -688,62 +746,117 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         launch_attenuation(s, g, B, d_tau, h->d_E, h->d_erep);
     }
     if (fast) HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), s));
-    double* In_1 = h->d_InA;
-    double* In = h->d_InB;
-    prof_begin(h, SOSRT_K_FIRST);
-    if (d_I1_in)
-        hipLaunchKernelGGL(k_init_from_I1, dim3(B), dim3(256), 0, s, g, d_I1_in, In_1, d_I_out, d_I_saved_out, saved_stride, cv);
-    else
-        launch_first_order(s, g, B, d_tau, d_P0_atm, d_P0_aer, h->d_desc, In_1, d_I_out, d_I_saved_out, saved_stride, cv, 1);
-    prof_end(h, SOSRT_K_FIRST);
-
-    // Order loop (spec:309-458).  Converged columns are masked on the device (every kernel of an
-    // order returns at once for them).  r_k = number of live columns after order k is written to a
-    // pinned slot by the first workgroup of order k+1's source-function launch; before launching order
-    // k+1 the host checks r_{k-1}, which is there as soon as order k has started, so the stream never
-    // drains inside the loop and at most one launch group runs on a fully converged batch.
-    int n = 1;
-    int known_active = B;                    // live columns after the last order the host has seen (lags by one)
-    const int tagbase = ((++h->pub_seq) & 0x3fff) << 16;      // tag of order n = tagbase + n
-    if (h->max_orders >= 65536) return fail(SOSRT_E_INVALID, "max_orders must be < 65536");
-    while (n < h->max_orders) {
-        if (n >= 2) {
-            const int live = wait_published(h, tagbase + n - 1);
-            if (live < 0) return live;
-            if (live == 0) break;
-            known_active = live;
-        }
-        ++n;
-        // this launch also publishes the live count after order n-1
-        run_source(h, In_1, h->d_Jn, h->d_active, (known_active < B && known_active <= h->gemm_tail_cols) ? known_active : 0,
-                   tagbase + n - 1);
-        if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
-            prof_begin(h, SOSRT_K_SMALLMU);
-            launch_smallmu(s, g, B, d_tau, h->d_Jn, In, h->d_desc, h->d_active);
-            prof_end(h, SOSRT_K_SMALLMU);
-        }
-        prof_begin(h, SOSRT_K_TRANSPORT);
-        double* sv_n = (d_I_saved_out && n <= h->saved_slots) ? d_I_saved_out + (size_t)(n - 1) * LD : nullptr;
-        if (fast) {
-            // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
-            // need not stage those rows either
-            Grid gt = g;
-            if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
-            launch_transport(s, gt, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, fast_mode, h->d_erep);
-            if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
-                launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1, h->d_E, 2, h->d_erep);
-        } else {
-            launch_transport(s, g, B, d_tau, h->d_Jn, In, d_I_out, sv_n, saved_stride, h->d_desc, cv, n, 1,
-                             h->use_etab ? h->d_E : nullptr, 0, h->d_erep);
-        }
-        prof_end(h, SOSRT_K_TRANSPORT);
-        double* tmp = In_1; In_1 = In; In = tmp;
+    if (h->mix_groups > 0 && h->mix_dirty) {
+        launch_wmix(s, (size_t)g.Dp * g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
+        h->mix_dirty = false;
     }
-    launch_finalize(s, B, cv, h->max_orders);
+    if (NG > 1) {                                    // the second column group runs on the internal stream from here on
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    }
+
+    // Order loop (spec:309-458), per column group.  Converged columns are masked on the device (every kernel of an
+    // order returns at once for them).  r_k = number of live columns of the group after order k is written to a
+    // pinned slot by the first workgroup of order k+1's source-function launch; before launching order k+1 the
+    // host checks r_{k-1}, which is there as soon as order k has started, so a stream never drains inside the loop
+    // and at most one launch group runs on a fully converged group.  With two groups the host feeds them in turn:
+    // each stream always holds the next order of its group, and the GPU overlaps the contraction of one group
+    // (MFMA-bound) with the transport of the other (HBM-bound).
+    struct GroupState {
+        int b0 = 0, nb = 0, n = 1, known = 0;
+        bool done = false, started = false;
+        double *In_1 = nullptr, *In = nullptr;
+        Conv cv;
+    } gs[sosrt_handle::kMaxGroups];
+    const int tagbase = ((++h->pub_seq) & 0x3fff) << 16;      // tag of order n = tagbase + n
+    for (int k = 0; k < NG; ++k) {
+        GroupState& q = gs[k];
+        q.b0 = h->gb[k]; q.nb = h->gb[k + 1] - h->gb[k]; q.known = q.nb;
+        q.In_1 = h->d_InA; q.In = h->d_InB;                   // whole-batch buffers; every kernel gets its group's offset
+        q.cv = make_conv(h, tol);
+        q.cv.active += q.b0; q.cv.norders += q.b0; q.cv.status += q.b0; q.cv.ratio += q.b0; q.cv.redo += q.b0;
+        q.cv.nactive = h->d_nactive + k;
+    }
+    auto start_group = [&](int k) {
+        GroupState& q = gs[k];
+        q.started = true;
+        hipStream_t sg = group_stream(h, k);
+        const size_t fo = (size_t)q.b0 * LD;
+        prof_begin(h, SOSRT_K_FIRST, k);
+        if (d_I1_in)
+            hipLaunchKernelGGL(k_init_from_I1, dim3(q.nb), dim3(256), 0, sg, g, d_I1_in + fo, q.In_1 + fo, d_I_out + fo,
+                               d_I_saved_out ? d_I_saved_out + (size_t)q.b0 * saved_stride : nullptr, saved_stride, q.cv);
+        else
+            launch_first_order(sg, g, q.nb, d_tau + (size_t)q.b0 * h->L, d_P0_atm + (size_t)q.b0 * g.D,
+                               d_P0_aer ? d_P0_aer + (size_t)q.b0 * g.D : nullptr, h->d_desc + q.b0, q.In_1 + fo, d_I_out + fo,
+                               d_I_saved_out ? d_I_saved_out + (size_t)q.b0 * saved_stride : nullptr, saved_stride, q.cv, 1);
+        prof_end(h, SOSRT_K_FIRST, k);
+    };
+    start_group(0);
+    int live_groups = NG, n_max = 1;
+    while (live_groups > 0) {
+        for (int k = 0; k < NG; ++k) {
+            GroupState& q = gs[k];
+            if (q.done) continue;
+            if (!q.started) {
+                // Staggered start: the dense orders of this group (they fill the GPU) run beside the long tail of the
+                // previous one (a few workgroups per order, latency-bound), instead of both being dense, then both in
+                // their tails, together.
+                const GroupState& p = gs[k - 1];
+                if (!(p.done || (p.n >= 2 && p.known <= h->stagger * p.nb))) continue;
+                start_group(k);
+            }
+            if (q.n >= h->max_orders) { q.done = true; --live_groups; continue; }
+            if (q.n >= 2) {
+                const int live = wait_published(h, k, tagbase + q.n - 1);
+                if (live < 0) return live;
+                if (live == 0) { q.done = true; --live_groups; continue; }
+                q.known = live;
+            }
+            const int n = ++q.n;
+            n_max = n > n_max ? n : n_max;
+            hipStream_t sg = group_stream(h, k);
+            const size_t fo = (size_t)q.b0 * LD;
+            // this launch also publishes the group's live count after order n-1
+            run_source(h, q.In_1, h->d_Jn, h->d_active, (q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0,
+                       tagbase + n - 1, k);
+            const double* tau_g = d_tau + (size_t)q.b0 * h->L;
+            if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
+                prof_begin(h, SOSRT_K_SMALLMU, k);
+                launch_smallmu(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, h->d_desc + q.b0, q.cv.active);
+                prof_end(h, SOSRT_K_SMALLMU, k);
+            }
+            prof_begin(h, SOSRT_K_TRANSPORT, k);
+            double* sv_n = (d_I_saved_out && n <= h->saved_slots) ? d_I_saved_out + (size_t)q.b0 * saved_stride + (size_t)(n - 1) * LD : nullptr;
+            const int* erep_g = h->d_erep + q.b0;     // values are whole-batch column ids; the table base is not offset
+            if (fast) {
+                // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
+                // need not stage those rows either
+                Grid gt = g;
+                if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
+                launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
+                                 h->d_E, fast_mode, erep_g);
+                if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
+                    launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
+                                     h->d_E, 2, erep_g);
+            } else {
+                launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
+                                 h->use_etab ? h->d_E : nullptr, 0, erep_g);
+            }
+            prof_end(h, SOSRT_K_TRANSPORT, k);
+            double* tmp = q.In_1; q.In_1 = q.In; q.In = tmp;
+        }
+    }
+    if (NG > 1) {                                    // back onto the caller's stream
+        HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+        HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+    }
+    prof_break(h);
+    launch_finalize(s, B, make_conv(h, tol), h->max_orders);
     HIPCHK(hipGetLastError());
     if (d_n_orders_out) HIPCHK(hipMemcpyAsync(d_n_orders_out, h->d_norders, B * sizeof(int), hipMemcpyDeviceToDevice, s));
     if (d_status_out) HIPCHK(hipMemcpyAsync(d_status_out, h->d_status, B * sizeof(int), hipMemcpyDeviceToDevice, s));
-    h->last_max_orders = n;
+    h->last_max_orders = n_max;
     h->last_sum_orders = -1;
     return 0;
 }
@@ -1076,38 +1189,41 @@ int sosrt_microbench(sosrt_t* h, int which, double* result) {
 // ---------------------------------------------------------------------------------------------
 int sosrt_profile_enable(sosrt_t* h, int on) {
     if (int e = need_gpu(h)) return e;
-    Prof& p = h->prof;
-    if (on && p.ev.empty()) {
-        HIPCHK(hipSetDevice(h->device));
-        p.ev.resize(2 * kProfPool);
-        p.kind.assign(kProfPool, -1); p.first.assign(kProfPool, 0); p.last.assign(kProfPool, 0);
-        // timing markers only: no system-scope fence (cache write-back / invalidate) at each of them
-        for (auto& e : p.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+    for (Prof& p : h->prof) {
+        if (on && p.ev.empty()) {
+            HIPCHK(hipSetDevice(h->device));
+            p.ev.resize(2 * kProfPool);
+            p.kind.assign(kProfPool, -1); p.first.assign(kProfPool, 0); p.last.assign(kProfPool, 0);
+            // timing markers only: no system-scope fence (cache write-back / invalidate) at each of them
+            for (auto& e : p.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+        }
+        p.on = on != 0;
     }
-    p.on = on != 0;
     return 0;
 }
 
 int sosrt_profile_reset(sosrt_t* h) {
     if (int e = need_gpu(h)) return e;
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->prof.used = 0; h->prof.nint = 0; h->prof.adjacent = -1; h->prof.open = -1;
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    for (Prof& p : h->prof) { p.used = 0; p.nint = 0; p.adjacent = -1; p.open = -1; }
     return 0;
 }
 
 int sosrt_profile_get(sosrt_t* h, int kernel, double* total_ms, long long* launches, double* work) {
     if (int e = need_gpu(h)) return e;
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream2));
     double tot = 0;
     long long cnt = 0;
-    Prof& p = h->prof;
-    for (size_t i = 0; i < p.nint; ++i) {
-        if (p.kind[i] != kernel) continue;
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, p.ev[p.first[i]], p.ev[p.last[i]]));
-        tot += ms;
-        ++cnt;
-    }
+    for (Prof& p : h->prof)
+        for (size_t i = 0; i < p.nint; ++i) {
+            if (p.kind[i] != kernel) continue;
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, p.ev[p.first[i]], p.ev[p.last[i]]));
+            tot += ms;
+            ++cnt;
+        }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = cnt;
     if (work) *work = 0;

@@ -272,7 +272,7 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     if (tid == 0) s_col = -1;
     int before = 0;
     for (int base = 0; base < g.B; base += 256) {
-        const bool f = base + tid < g.B && g.active[base + tid] != 0;
+        const bool f = base + tid < g.B && g.active[g.col0 + base + tid] != 0;
         const unsigned long long mk = __ballot(f);
         if (lane == 0) s_w[wave] = __popcll(mk);
         __syncthreads();
@@ -281,7 +281,7 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
             if (w < wave) pre += s_w[w];
             tot += s_w[w];
         }
-        if (f && pre + __popcll(mk & ((2ull << lane) - 1)) == ci + 1) s_col = base + tid;
+        if (f && pre + __popcll(mk & ((2ull << lane) - 1)) == ci + 1) s_col = g.col0 + base + tid;
         before += tot;
         __syncthreads();
         if (before > ci) break;

@@ -130,7 +130,8 @@ struct GemmArgs {
     // k_jn_gemm_tail only: tiles are laid over the live columns (the i-th group of workgroups finds the
     // i-th live column itself), not over the row lists
     int B = 0;
-    const int* idx_up = nullptr;     // [B] first / last slab row of a column; null: no slab rows
+    int col0 = 0;                    // the launch covers the columns [col0, col0 + B) of the batch (all per-column arrays are whole-batch)
+    const int* idx_up = nullptr;     // [batch] first / last slab row of a column; null: no slab rows
     const int* idx_down = nullptr;
     int max_main = 0, max_slab = 0;  // most plain / slab rows any column has
     const double* Wmix = nullptr;    // [groups][Dp][Wld] ca W_atm + cr W_aer per distinct slab coefficient pair; null: two passes
@@ -139,7 +140,8 @@ struct GemmArgs {
     // The order loop's view of the batch: the first workgroup of the source-function launch of order
     // n+1 (which starts when order n has finished) writes {live columns after order n, tag} to pinned
     // host memory, where the host spins on the tag -- no copy, no event, no stream drain.
-    const int* nactive = nullptr;    // [2]: live columns, and whether any column needs k_smallmu (set by k_prepare)
+    const int* nactive = nullptr;    // [1]: live columns of this column group
+    const int* need_small = nullptr; // [1]: whether any column of the batch needs k_smallmu (set by k_prepare)
     int* host_pub = nullptr;         // pinned [2 slots][4] = {live, tag, needs k_smallmu, -}; slot = tag & 1
     int tag = 0;
 };
@@ -149,7 +151,7 @@ __device__ inline void publish_live(const GemmArgs& g) {
         const int live = __hip_atomic_load(g.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int* slot = g.host_pub + 4 * (g.tag & 1);
         __hip_atomic_store(slot, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(slot + 2, g.nactive[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(slot + 2, g.need_small ? g.need_small[0] : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(slot + 1, g.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

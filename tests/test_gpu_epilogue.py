@@ -162,18 +162,18 @@ def test_device_phase_builders_match_reference():
 def test_device_p0_sweep_feeds_the_solve():
     """P0 built on the device for every column of a mu0 sweep and handed to the solve without leaving HBM."""
     torch = pytest.importorskip("torch")
-    L, N, B = 40, 32, 6
+    L, N, B = 40, 64, 6
     dev = torch.device("cuda", 0)
     mu = inputs.direction_grid(N)
     mu0 = np.linspace(0.25, 0.95, B)
     iu, idn = inputs.slab_indices(120, 25, 17, L)
-    tau = np.stack([inputs.tau_profile(0.124, 0.3, 120, 25, 17, L)] * B)
+    tau = np.stack([inputs.tau_profile(0.124, 0.12, 120, 25, 17, L)] * B)
     P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
     P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
     s = Solver(L, N, max_batch=B, max_orders=64)
     s.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     s.set_grid(mu); s.set_phase(P_atm, P_aer)
-    s.set_columns(np.full(B, iu), np.full(B, idn), mu0, 0.2, 1.0, 0.95, 0.124 / L, 0.3 / (idn + 1 - iu), 0.424)
+    s.set_columns(np.full(B, iu), np.full(B, idn), mu0, 0.15, 1.0, 0.95, 0.124 / L, 0.12 / (idn + 1 - iu), 0.244)
     d_mu0 = torch.from_numpy(mu0).to(dev)
     d_P0a = torch.empty((B, 2 * N), dtype=torch.float64, device=dev)
     d_P0r = torch.empty((B, 2 * N), dtype=torch.float64, device=dev)
@@ -188,7 +188,7 @@ def test_device_p0_sweep_feeds_the_solve():
     for b in (0, B - 1):
         P0a, _ = O.phase_rayleigh(N, mu, mu0[b])
         P0r, _ = O.phase_hg(N, mu, mu0[b], 0.7)
-        col = O.make_column(mu0[b], 120, 25, 17, L, 0.124, 0.3, 0.2, 1.0, 0.95, N, P0a, P_atm, P0r, P_aer)
+        col = O.make_column(mu0[b], 120, 25, 17, L, 0.124, 0.12, 0.15, 1.0, 0.95, N, P0a, P_atm, P0r, P_aer)
         ref = O.solve_column(col, literal=False)
         assert ref.n == int(d_n[b])
         assert_close(I[b], ref.I, RTOL, "column %d" % b)

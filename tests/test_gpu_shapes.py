@@ -180,7 +180,11 @@ def test_c5_full_size_batch_on_device():
     s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
                   w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
     d_tau = torch.from_numpy(w["tau"]).to(dev)
-    d_P0a = torch.from_numpy(w["P0a"]).to(dev); d_P0r = torch.from_numpy(w["P0r"]).to(dev)
+    # P0(mu, mu0) of the 4096 columns built on the device (16 distinct mu0)
+    d_mu0 = torch.from_numpy(np.ascontiguousarray(w["mu0"])).to(dev)
+    d_P0a = torch.empty((B, 2 * N), dtype=torch.float64, device=dev); d_P0r = torch.empty((B, 2 * N), dtype=torch.float64, device=dev)
+    s.phase_p0_device("rayleigh", d_mu0.data_ptr(), d_P0a.data_ptr(), B)
+    s.phase_p0_device("hg", d_mu0.data_ptr(), d_P0r.data_ptr(), B, g=0.7)
     d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
     digests = []
@@ -198,7 +202,7 @@ def test_c5_full_size_batch_on_device():
     b = 16 * 16 * 5 + 16 * 9 + 4
     mu = w["mu"]
     col = O.make_column(w["mu0"][b], 120, 25, 17, L, w["tau_atm"], w["taer"][b], w["rho"][b], 1.0, w["alb_aer"], N,
-                        w["P0a"][b], w["P_atm"], w["P0r"][b], w["P_aer"])
+                        O.phase_rayleigh(N, mu, w["mu0"][b])[0], w["P_atm"], O.phase_hg(N, mu, w["mu0"][b], 0.7)[0], w["P_aer"])
     ref = O.solve_column(col, literal=False)
     assert int(d_n[b].item()) == ref.n
     assert_close(d_I[b].cpu().numpy(), ref.I, RTOL, "column %d" % b)
