@@ -100,6 +100,7 @@ struct sosrt_handle {
     double *d_Wmix = nullptr, *d_mixca = nullptr, *d_mixcr = nullptr;
     int* d_mixgroup = nullptr;
     int* d_slabtilegroup = nullptr;      // [tiles] group of every 32-row slab tile of the dense contraction
+    int* d_livelist = nullptr;           // [max_batch] live columns of the current order, written by the source-function launch
     size_t mix_capacity = 0;
     // device: fields (internal)
     double *d_tau = nullptr, *d_P0a = nullptr, *d_P0r = nullptr;
@@ -270,6 +271,7 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
         ga.col0 = h->nslab > 0 ? h->gb[g0] : 0; ga.B = h->gb[g1] - h->gb[g0];
         ga.max_main = h->max_main; ga.max_slab = h->max_slab;
         ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
+        ga.live_list = h->d_livelist + h->gb[g0]; ga.live_cap = tail_cols;
         launch_gemm_tail(s, ga, tail_cols, tail_cols <= h->gemm_small_cols);
     } else {
         launch_gemm(s, ga);
@@ -359,6 +361,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_redo, mb))) return e;
             if ((e = dalloc(&h->d_erep, mb))) return e;
             if ((e = dalloc(&h->d_mixgroup, mb))) return e;
+            if ((e = dalloc(&h->d_livelist, mb))) return e;
             if ((e = dalloc(&h->d_mixca, sosrt_handle::kMaxMixGroups))) return e;
             if ((e = dalloc(&h->d_mixcr, sosrt_handle::kMaxMixGroups))) return e;
             if ((e = dalloc(&h->d_tauhash, mb))) return e;
@@ -390,7 +393,7 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup};
+                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -818,8 +821,8 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             hipStream_t sg = group_stream(h, k);
             const size_t fo = (size_t)q.b0 * LD;
             // this launch also publishes the group's live count after order n-1
-            run_source(h, q.In_1, h->d_Jn, h->d_active, (q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0,
-                       tagbase + n - 1, k);
+            const int tail_cols = (q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
+            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
                 prof_begin(h, SOSRT_K_SMALLMU, k);
@@ -835,7 +838,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 Grid gt = g;
                 if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
-                                 h->d_E, fast_mode, erep_g);
+                                 h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0);
                 if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
                     launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                      h->d_E, 2, erep_g);

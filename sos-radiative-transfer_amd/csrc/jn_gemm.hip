@@ -287,6 +287,8 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
         if (before > ci) break;
     }
     const int b = s_col;
+    // the transport of this order takes its columns from this list
+    if (g.live_list && tt == 0 && bn0 == 0 && tid == 0 && ci < g.live_cap) g.live_list[ci] = b < 0 ? -1 : b - g.col0;
     if (b < 0) return;                                   // fewer live columns than the host's (lagging) count
     const int iu = g.idx_up ? g.idx_up[b] : 0;
     const int ns = g.idx_up ? g.idx_down[b] - iu + 1 : 0;

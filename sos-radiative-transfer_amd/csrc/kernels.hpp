@@ -98,6 +98,13 @@ struct TransportArgs {
     const double* Etab;
     const int* erep;           // [B] column whose attenuation table this column uses (same tau profile); null: its own
     unsigned long long* stamps;   // diagnostic builds only: [B][8] cycle stamps of the sweeps (nullable)
+    // ring kernel, some columns converged: `live` > 0 launches workgroups for (an upper bound of) the live columns only;
+    // workgroup i takes column live_list[i], the list the source-function launch of the same order wrote (the flags
+    // themselves change while the transport runs).  Besides skipping the idle workgroups this spreads the live
+    // columns evenly over the XCDs (workgroups are dealt round-robin over them, and the slow-converging columns of a
+    // sweep tend to share their index modulo 8).
+    int live = 0;
+    const int* live_list = nullptr;
 };
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
@@ -136,6 +143,8 @@ struct GemmArgs {
     int max_main = 0, max_slab = 0;  // most plain / slab rows any column has
     const double* Wmix = nullptr;    // [groups][Dp][Wld] ca W_atm + cr W_aer per distinct slab coefficient pair; null: two passes
     const int* mix_group = nullptr;  // [B] group of a column
+    int* live_list = nullptr;        // live-column tilings: [live_cap] the i-th live column (relative to col0), -1 beyond the live count
+    int live_cap = 0;
     const int* slab_tile_group = nullptr;   // dense kernel: group of every 32-row tile of rows_slab (listed group by group, padded with -1)
     // The order loop's view of the batch: the first workgroup of the source-function launch of order
     // n+1 (which starts when order n has finished) writes {live columns after order n, tag} to pinned
@@ -165,7 +174,7 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
-                      const double* Etab, int mode, const int* erep = nullptr);
+                      const double* Etab, int mode, const int* erep = nullptr, int live = 0, const int* live_list = nullptr);
 bool transport_fast_ok(const Plan& plan);
 // erep (nullable): tables are built only for columns with erep[b] == b
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep);

@@ -53,8 +53,13 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     constexpr int dbg = 0;
     (void)dbg_arg;
 #endif
-    const int b = blockIdx.x;
-    if (ACC && !a.cv.active[b]) return;
+    int b = blockIdx.x;
+    if (ACC && a.live > 0) {
+        b = a.live_list[blockIdx.x];
+        if (b < 0) return;                          // fewer live columns than the host's (lagging) count
+    } else if (ACC && !a.cv.active[b]) {
+        return;
+    }
     const Grid& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
