@@ -257,17 +257,17 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 const int t = SP ? min(t0 + u, L - 1) : t0 + u;
                 const double hk = s_hd[t];
                 const double Jp = u == 0 ? Jprev : Jc[u - 1];
-                cc[u] = (hk * nrmu) * (Jp * Ec[u] + Jc[u]);
+                cc[u] = rec_src(rec_hr(hk, nrmu), Jp, Ec[u], Jc[u]);
             }
             if (!SP) {
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
-                    Dv = Dv * Ec[u] + cc[u];
+                    Dv = rec_step(Dv, Ec[u], cc[u]);
                     v[u] = Dv;
                 }
                 if (has_small) {
 #pragma unroll
-                    for (int u = 0; u < TC; ++u) v[u] += Sc[u];
+                    for (int u = 0; u < TC; ++u) v[u] = rec_add(v[u], Sc[u]);
                 }
                 // In_limit:113-141 as a linear map of the source lanes.  Up to 8 rewritten directions: the
                 // chunk goes through LDS and work item (uT, pT) does row uT, direction N-1-pT -- one pass for
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     for (int u = 0; u < TC; ++u) s_x[u * 64 + lane] = v[u];
                     double acc = 0;
 #pragma unroll
-                    for (int k = 0; k < kFixMaxSrc; ++k) acc += cT[k] * xrow[sl[k]];
+                    for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(cT[k], xrow[sl[k]], acc);
                     const int mT = N - 1 - pT;
                     const double IcT = ACC ? slot[(2 * TC + uT) * RS + max(mT, 0)] : 0.0;
                     if (pT < nfx) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     for (int u = 0; u < TC; ++u) {
                         double acc = 0;
 #pragma unroll
-                        for (int k = 0; k < kFixMaxSrc; ++k) acc += c[k] * readlane_f64(v[u], sl[k]);
+                        for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(c[k], readlane_f64(v[u], sl[k]), acc);
                         v[u] = fixlane ? acc : v[u];
                     }
                 }
@@ -310,12 +310,12 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 for (int u = 0; u < TC; ++u) {
                     const int t = t0 + u;
                     if (wl && (t == zbeg1 || t == zbeg2)) load_fix(t == zbeg1 ? 1 : 2);
-                    const double Dn = Dv * Ec[u] + cc[u];
-                    double x = has_small ? Dn + Sc[u] : Dn;
+                    const double Dn = rec_step(Dv, Ec[u], cc[u]);
+                    double x = has_small ? rec_add(Dn, Sc[u]) : Dn;
                     if (wl && nfx > 0) {
                         double acc = 0;
 #pragma unroll
-                        for (int k = 0; k < kFixMaxSrc; ++k) acc += c[k] * readlane_f64(x, sl[k]);
+                        for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(c[k], readlane_f64(x, sl[k]), acc);
                         x = fixlane ? acc : x;
                     }
                     v[u] = x;
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             const int kf = mk ? __ffsll((long long)mk) : 1;
             notfound |= (mk == 0);
             const double r0 = readlane_f64(x, 0), rk = readlane_f64(x, kf);
-            const double w = mu * readlane_f64(prmu, kf);              // mu_m / mu_kf to one rounding
-            const double bl = (1 - w) * r0 + w * rk;
+            const double w = blend_weight(mu, readlane_f64(prmu, kf));         // mu_m / mu_kf
+            const double bl = blend_val(w, r0, rk);
             return (tr && tid < kf) ? bl : x;
         };
         int t0 = L - 1, q = NCH;
@@ -410,14 +410,14 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 const int t = SP ? max(t0 - u, 0) : t0 - u;
                 const double hk = s_hd[t + 1];
                 const double Jx = u == 0 ? Jnext : Jc[u - 1];
-                const double src = (hk * prmu) * (Jc[u] + Jx * Ec[u]);
+                const double src = rec_src(rec_hr(hk, prmu), Jx, Ec[u], Jc[u]);
                 // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
                 cc[u] = (SP && (t == zend0 || t == zend1)) ? 0.0 : src;
             }
             if (!SP) {
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
-                    U = U * Ec[u] + cc[u];
+                    U = rec_step(U, Ec[u], cc[u]);
                     v[u] = U;
                 }
                 // spec:401-409.  The search almost always ends within the first few directions: the chunk goes
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     if (tblend) {
                         const int kf = __ffs((int)bits) + 1;                     // ks + 1, <= 9
                         const double r0 = xrow[0], rk = xrow[kf];
-                        const double w = muT * s_prmu[kf];                       // mu_m / mu_kf to one rounding
-                        const double bl = (1 - w) * r0 + w * rk;
+                        const double w = blend_weight(muT, s_prmu[kf]);              // mu_m / mu_kf
+                        const double bl = blend_val(w, r0, rk);
                         const double val = k < kf ? bl : xa;
                         const double IcT = ACC ? slot[(2 * TC + uT) * RS + k] : 0.0;
                         if (k < N) {
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
                     const int t = t0 - u;
-                    const double Un = U * Ec[u] + cc[u];
+                    const double Un = rec_step(U, Ec[u], cc[u]);
                     double x = Un;
                     if (w0 && t >= 0) x = blend(tid == 0 ? Jc[u] : Un);
                     v[u] = x;

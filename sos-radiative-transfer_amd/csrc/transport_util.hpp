@@ -31,6 +31,19 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int s
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// two adjacent doubles per lane (16 bytes): half the vector-memory instructions of the 8-byte forms
+__device__ __forceinline__ double2 bload2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+__device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, int voff, int soff, double2 x) {
+    u32x4 v;
+    v.x = (unsigned)__double2loint(x.x); v.y = (unsigned)__double2hiint(x.x);
+    v.z = (unsigned)__double2loint(x.y); v.w = (unsigned)__double2hiint(x.y);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
 // value of lane + 1 (wave_shl:1); lane 63 keeps its own
 __device__ __forceinline__ double lane_up1(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -49,6 +62,37 @@ __device__ __forceinline__ double wave_sum_(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// The arithmetic of the sweeps, spelled out operation by operation (no contraction left to the compiler): the ring
+// kernel and the pipeline kernel must produce the same bits, because which of them transports a column depends on
+// how many columns of its batch are still live.
+//   source term of a row (spec:336-340, 393-399):  (h / |mu|) (Ja E + Jb),  h = half the layer thickness
+__device__ __forceinline__ double rec_src(double h_rmu, double Ja, double E, double Jb) {
+#pragma clang fp contract(off)
+    return h_rmu * __builtin_fma(Ja, E, Jb);
+}
+__device__ __forceinline__ double rec_hr(double h, double rmu) {
+#pragma clang fp contract(off)
+    return h * rmu;
+}
+//   one step of the recurrence:  S E + c
+__device__ __forceinline__ double rec_step(double S, double E, double c) { return __builtin_fma(S, E, c); }
+__device__ __forceinline__ double rec_add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+//   spec:407-409:  (1 - w) r0 + w rk,  w = mu_m / mu_k as mu_m * (1 / mu_k)
+__device__ __forceinline__ double blend_weight(double mu_m, double rmu_k) {
+#pragma clang fp contract(off)
+    return mu_m * rmu_k;
+}
+__device__ __forceinline__ double blend_val(double w, double r0, double rk) {
+#pragma clang fp contract(off)
+    const double a = (1 - w) * r0;
+    return __builtin_fma(w, rk, a);
+}
+//   In_limit:113-141 as a linear map: acc + c x
+__device__ __forceinline__ double fix_acc(double c, double x, double acc) { return __builtin_fma(c, x, acc); }
 
 // Python's max() over a row (see block_pymax in kernels.hip); first_tid holds element 0.
 __device__ double block_pymax_(double x, bool valid, double* s_red, int first_tid) {
