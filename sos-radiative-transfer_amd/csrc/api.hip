@@ -109,9 +109,7 @@ struct sosrt_handle {
     // convergence
     int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr, *d_erep = nullptr;
     unsigned long long* d_tauhash = nullptr;
-    int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel, pipeline kernel below
-                                         // SOSRT_PIPE_MAX live columns (+ repair), 3: pipeline kernel always (tests)
-    bool pipe_ok = false;
+    int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel (+ repair)
     bool ring_ok = false;
     int gemm_tail_cols = 1 << 30;        // at or below this many live columns (and below the batch) tiles are laid over live columns (SOSRT_GEMM_TAIL)
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
@@ -304,9 +302,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     h->gpu = device >= 0;
     if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
-        h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : (strcmp(ev, "pipe") == 0 ? 3 : 1));
-    if (const char* ev = getenv("SOSRT_PIPE_MAX")) g_pipe_max = atoi(ev);
-    if (const char* ev = getenv("SOSRT_PIPE_SLOTS")) g_pipe_slots = atoi(ev);
+        h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : 1);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
@@ -475,7 +471,6 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
         if (h->g.nsmall)
             HIPCHK(hipMemcpy(h->d_small, h->plan.small_lanes.data(), h->g.nsmall * sizeof(int), hipMemcpyHostToDevice));
         h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
-        h->pipe_ok = h->ring_ok && transport_pipe_ok(h->g);
     }
     return 0;
 }
@@ -681,7 +676,7 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
         launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E, nullptr);
         HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E,
-                         (h->transport_mode == 3 && h->pipe_ok) ? 4 : ((h->transport_mode >= 2 && h->ring_ok) ? 3 : 1));
+                         (h->transport_mode == 2 && h->ring_ok) ? 3 : 1);
         if (h->N - 3 > 61)
             launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 2);
     } else {
@@ -747,7 +742,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                    h->d_nactive + sosrt_handle::kMaxGroups);
     h->need_small = true;
     const bool fast = h->transport_mode >= 1 && h->fast_ok;
-    const int fast_mode = (h->transport_mode == 3 && h->pipe_ok) ? 4 : ((h->transport_mode >= 2 && h->ring_ok) ? 3 : 1);
+    const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) {
         // one attenuation table per distinct optical-depth profile
         launch_tau_groups(s, g, B, d_tau, h->d_tauhash, h->d_erep);
@@ -841,7 +836,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
                 // need not stage those rows either
                 Grid gt = g;
-                if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
+                if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0);
                 if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)

@@ -806,12 +806,9 @@ void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, u
 template <int MAXT>
 static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm, const TransportArgs& a, int mode) {
     // mode 0: general kernel, 1: wave-independent fast kernel, 2: general kernel repairing flagged columns,
-    // 3: the fast kernel's sweeps fed through an LDS ring -- or, with fewer live columns than compute units, through
-    // the pipeline of specialised waves; 4: the pipeline kernel whatever the number of columns
+    // 3: the fast kernel's sweeps fed through an LDS ring
     if (mode == 1) {
         launch_transport_fast(s, grid, block, a);
-    } else if (mode == 4 || (mode == 3 && a.live > 0 && a.live <= g_pipe_max && transport_pipe_ok(a.g))) {
-        launch_transport_pipe(s, grid, a, g_pipe_slots);
     } else if (mode == 3) {
         launch_transport_ring(s, grid, a, g_ring_slots, g_ring_loaders);
     } else if (mode == 2) {
@@ -852,7 +849,7 @@ void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, co
     const int nt = round64(g.N);
     const size_t shm = (size_t)(g.L + 2 * TC * (nt + 2) + 2 * nt + nt / 64 + 2) * sizeof(double);
     TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab, Etab ? erep : nullptr, g_transport_stamps};
-    if ((mode == 3 || mode == 4) && accumulate && live > 0 && live < B && live_list) {       // ring / pipeline kernel over the live columns only
+    if (mode == 3 && accumulate && live > 0 && live < B && live_list) {       // ring kernel over the live columns only
         a.live = live;
         a.live_list = live_list;
         B = live;

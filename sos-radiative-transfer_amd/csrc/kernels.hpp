@@ -111,10 +111,6 @@ void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const Transport
 bool transport_ring_ok(const Grid& g);
 void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots, int loaders);
 extern int g_ring_slots, g_ring_loaders, g_ring_debug;        // tuning (SOSRT_RING_SLOTS, SOSRT_RING_LOADERS)
-// transport_pipe.hip: the same sweeps as a pipeline of specialised waves, for fewer live columns than compute units
-bool transport_pipe_ok(const Grid& g);
-void launch_transport_pipe(hipStream_t s, dim3 grid, const TransportArgs& a, int slots);
-extern int g_pipe_max, g_pipe_slots;                           // SOSRT_PIPE_MAX, SOSRT_PIPE_SLOTS
 extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
 
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,

@@ -16,11 +16,10 @@ from util import RTOL, assert_close, column_case, g1_case, golden, oracle_column
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fast", "ring", "pipe", "general"])
+@pytest.fixture(params=["fast", "ring", "general"])
 def transport_mode(request, monkeypatch):
     """The transport kernels: the wave-independent one (+ repair), the same fed through an LDS ring by
-    loader waves, the pipeline of specialised waves (N <= 128; the ring kernel beyond), and the general
-    LDS-exchange one."""
+    loader waves, and the general LDS-exchange one."""
     monkeypatch.setenv("SOSRT_TRANSPORT", request.param)
     for s in list(I1_In._handles.values()):
         s.close()
@@ -313,25 +312,3 @@ def test_mixed_slab_geometries_and_shared_profiles_in_one_batch(transport_mode):
         assert r.n[b] == ref.n, (b, r.n[b], ref.n)
         assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
 
-
-def test_pipeline_kernel_equals_ring_kernel_bit_for_bit(monkeypatch):
-    """Which of the two kernels transports a column depends on how many columns of its batch are still live, so the
-    two must agree to the last bit (a column's result must not depend on the batch it is solved in)."""
-    rng = np.random.default_rng(11)
-    B = 24
-    mu0 = rng.uniform(0.2, 1.0, B)
-    taer = rng.choice([0.02, 0.1, 0.35, 0.9, 2.5], B)
-    rho = rng.uniform(0.0, 0.8, B)
-    res = {}
-    for surface in ("specular", "lambertian"):
-        for N in (128, 64, 30):
-            kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=57, nb_angles=N, max_orders=200, surface=surface,
-                      save_orders=(N == 30), raise_on_error=False)
-            for mode in ("ring", "pipe"):
-                monkeypatch.setenv("SOSRT_TRANSPORT", mode)
-                res[mode] = SOS_Aer_batch(mu0, taer, rho, **kw)
-            a, b = res["ring"], res["pipe"]
-            assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status), (surface, N)
-            assert np.array_equal(a.I, b.I), (surface, N, float(np.max(np.abs(a.I - b.I))))
-            if a.I_saved is not None:
-                assert np.array_equal(a.I_saved, b.I_saved)

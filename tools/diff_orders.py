@@ -12,7 +12,7 @@ N = int(os.environ.get("NANG", "128"))
 SAVE = os.environ.get("SAVE", "1") == "1"
 kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=int(os.environ.get("NLAY", "57")), nb_angles=N, max_orders=200, save_orders=SAVE, raise_on_error=False)
 res = {}
-for mode in sys.argv[1:] or ["ring", "pipe"]:
+for mode in sys.argv[1:] or ["ring", "fast"]:
     os.environ["SOSRT_TRANSPORT"] = mode
     res[mode] = SOS_Aer_batch(mu0, taer, rho, **kw)
 a, b = list(res.values())[:2]
