@@ -49,7 +49,10 @@ typedef struct sosrt_handle sosrt_t;
 /* surface model for orders n >= 2 */
 #define SOSRT_SURFACE_NONE       0  /* single slab (I1_In:86-98)                                       */
 #define SOSRT_SURFACE_SPECULAR   1  /* spec:397/399                                                    */
-#define SOSRT_SURFACE_LAMBERTIAN 2  /* lam:399/401, coded sign (SURVEY hazard H2)                      */
+#define SOSRT_SURFACE_LAMBERTIAN 2  /* lam:399/401, coded sign (SURVEY hazard H2): the reflected radiance comes
+                                       out negative, because the code integrates over a descending mu array      */
+#define SOSRT_SURFACE_LAMBERTIAN_README 3  /* the same term with the sign of README.md:215 (positive); not what the
+                                              reference's file computes -- non-default, parity unpinned            */
 
 const char* sosrt_last_error(void);
 int sosrt_version(void);
@@ -152,6 +155,24 @@ int sosrt_phase_p0_dev(sosrt_t* h, int B, int kind, double g, const double* d_mu
 int sosrt_phase_p0(sosrt_t* h, int B, int kind, double g, const double* mu0, double* P0_out);
 /* P(mu, mu') [2N][2N] row-major with the column normalisation trapz(P[:, n], mu) = 4 (phase:107-131); host output */
 int sosrt_phase_matrix(sosrt_t* h, int kind, double g, double* P_out);
+
+/* ---- multi-GPU: one process per GPU, columns sharded, ONE collective at the end ------------------
+ * Nothing in SOS_Aer_main_specular.py:104-458 couples columns, so the order loop never communicates; these entry
+ * points only assemble the results of the ranks on `root` over RCCL (xGMI inside a node).  RCCL is bound at run time
+ * (dlopen): the library has no link-time dependency on it.
+ *   sosrt_comm_unique_id  rank 0 fills id_out[128] (ncclGetUniqueId); the caller hands it to the other ranks by any
+ *                         means (file, MPI, torch.distributed store, environment).
+ *   sosrt_comm_init       every rank, same id: ncclCommInitRank on the handle's device.
+ *   sosrt_gather          every rank: counts[world] doubles per rank (ragged shards allowed, counts[r] may be 0),
+ *                         d_send = this rank's counts[rank] doubles (device), d_recv on root = the ranks' blocks one
+ *                         after the other (device, sum of counts; ignored elsewhere).  Enqueued on the handle's stream
+ *                         as ncclSend / ncclRecv pairs in one group -- a gather over the point-to-point links, each
+ *                         sender on its own link to the root.
+ *   sosrt_comm_destroy    ncclCommDestroy. */
+int sosrt_comm_unique_id(void* id_out);
+int sosrt_comm_init(sosrt_t* h, int rank, int world, const void* unique_id);
+int sosrt_gather(sosrt_t* h, int root, const long long* counts, const double* d_send, double* d_recv);
+int sosrt_comm_destroy(sosrt_t* h);
 
 /* ---- helper level (In_limit:70,113) on device, host pointers -------------------------------- */
 /* rows [R][N] of downward radiances; returns the idx rewritten values per row: out [R][idx] with

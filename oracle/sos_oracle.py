@@ -362,6 +362,8 @@ def _transport(Jn, tau, mu, N, zones: Sequence[_Zone], tau_ref: Sequence[float],
                         B = grd_alb * In[L - 1, rev]
                     elif surface == "lambertian":
                         B = -2 * grd_alb * _trapz(In[L - 1, rev] * mu[rev], mu[rev])
+                    elif surface == "lambertian_readme":        # README.md:215: the same integral over ascending mu
+                        B = 2 * grd_alb * _trapz(In[L - 1, rev] * mu[rev], mu[rev])
                     else:
                         B = 0.0
                     tb = tau[L - 1]

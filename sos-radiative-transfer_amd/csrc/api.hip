@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/sosrt.h"
+#include "comm.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
 
@@ -121,6 +122,9 @@ struct sosrt_handle {
     int last_max_orders = 0;
     long long last_sum_orders = 0;
     Prof prof[kMaxGroups];               // per column group (= per stream)
+    // RCCL communicator of the sharded solve (sosrt_comm_init)
+    Rccl::comm_t comm = nullptr;
+    int comm_rank = -1, comm_world = 0;
 };
 
 namespace {
@@ -388,6 +392,7 @@ int sosrt_destroy(sosrt_t* h) {
     if (!h) return 0;
     if (h->gpu) {
         hipSetDevice(h->device);
+        if (h->comm) { rccl().CommDestroy(h->comm); h->comm = nullptr; }
         if (h->own_stream) hipStreamSynchronize(h->own_stream);
         void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
@@ -508,7 +513,7 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
     if (geometry == SOSRT_GEOM_THREE_ZONE) {
         if (!idx_up || !idx_down || !grd_alb || !alb_aer || !dtau_atm || !dtau_aer)
             return fail(SOSRT_E_INVALID, "three-zone geometry needs idx_up, idx_down, grd_alb, alb_aer, dtau_atm, dtau_aer");
-        if (surface != SOSRT_SURFACE_SPECULAR && surface != SOSRT_SURFACE_LAMBERTIAN)
+        if (surface != SOSRT_SURFACE_SPECULAR && surface != SOSRT_SURFACE_LAMBERTIAN && surface != SOSRT_SURFACE_LAMBERTIAN_README)
             return fail(SOSRT_E_INVALID, "three-zone geometry needs a specular or lambertian surface");
         for (int b = 0; b < B; ++b) {
             if (idx_up[b] < 1 || idx_down[b] < idx_up[b] || idx_down[b] > h->L - 2)
@@ -1055,6 +1060,80 @@ int sosrt_phase_matrix(sosrt_t* h, int kind, double g, double* P_out) {
     rc = body();
     hipFree(dP);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU gather over RCCL
+// ---------------------------------------------------------------------------------------------
+#define NCCLCHK(x)                                                                                          \
+    do {                                                                                                    \
+        const int r_ = (x);                                                                                 \
+        if (r_ != 0) return fail(SOSRT_E_HIP, "%s failed: %s", #x, rccl().GetErrorString(r_));              \
+    } while (0)
+
+int sosrt_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(SOSRT_E_INVALID, "null argument");
+    if (const char* e = rccl().load()) return fail(SOSRT_E_STATE, "%s", e);
+    Rccl::UniqueId id;
+    NCCLCHK(rccl().GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int sosrt_comm_init(sosrt_t* h, int rank, int world, const void* unique_id) {
+    if (int e = need_gpu(h)) return e;
+    if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(SOSRT_E_INVALID, "bad rank / world / id");
+    if (h->comm) return fail(SOSRT_E_STATE, "the handle already has a communicator");
+    if (const char* e = rccl().load()) return fail(SOSRT_E_STATE, "%s", e);
+    HIPCHK(hipSetDevice(h->device));
+    Rccl::UniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    NCCLCHK(rccl().CommInitRank(&h->comm, world, id, rank));
+    h->comm_rank = rank; h->comm_world = world;
+    return 0;
+}
+
+int sosrt_gather(sosrt_t* h, int root, const long long* counts, const double* d_send, double* d_recv) {
+    if (int e = need_gpu(h)) return e;
+    if (!h->comm) return fail(SOSRT_E_STATE, "sosrt_comm_init has not been called");
+    if (!counts || root < 0 || root >= h->comm_world) return fail(SOSRT_E_INVALID, "bad root / counts");
+    for (int r = 0; r < h->comm_world; ++r)
+        if (counts[r] < 0) return fail(SOSRT_E_INVALID, "counts[%d] < 0", r);
+    const int me = h->comm_rank;
+    if (counts[me] > 0 && !d_send) return fail(SOSRT_E_INVALID, "d_send is null");
+    if (me == root && !d_recv) return fail(SOSRT_E_INVALID, "d_recv is null on the root");
+    HIPCHK(hipSetDevice(h->device));
+    const int kF64 = 8;                                      // ncclFloat64
+    NCCLCHK(rccl().GroupStart());
+    if (me == root) {
+        size_t off = 0;
+        for (int r = 0; r < h->comm_world; ++r) {
+            if (counts[r] > 0) {
+                if (r == me) {
+                    if (d_recv + off != d_send)
+                        HIPCHK(hipMemcpyAsync(d_recv + off, d_send, (size_t)counts[r] * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                } else {
+                    NCCLCHK(rccl().Recv(d_recv + off, (size_t)counts[r], kF64, r, h->comm, h->stream));
+                }
+            }
+            off += (size_t)counts[r];
+        }
+    } else if (counts[me] > 0) {
+        NCCLCHK(rccl().Send(d_send, (size_t)counts[me], kF64, root, h->comm, h->stream));
+    }
+    NCCLCHK(rccl().GroupEnd());
+    return 0;
+}
+
+int sosrt_comm_destroy(sosrt_t* h) {
+    if (int e = need_gpu(h)) return e;
+    if (h->comm) {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        NCCLCHK(rccl().CommDestroy(h->comm));
+        h->comm = nullptr; h->comm_rank = -1; h->comm_world = 0;
+    }
+    return 0;
 }
 
 int sosrt_limit_mu_down(sosrt_t* h, int R, int idx, const double* rows, double* out) {

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     double Bv = 0;
     if (d.surface == SOSRT_SURFACE_SPECULAR) {
         Bv = valid ? d.rho * s_sfc[N - 1 - tid] : 0.0;              // spec:397
-    } else if (d.surface == SOSRT_SURFACE_LAMBERTIAN) {
+    } else if (d.surface == SOSRT_SURFACE_LAMBERTIAN || d.surface == SOSRT_SURFACE_LAMBERTIAN_README) {
         // -2 rho trapz(In[L-1, rev] mu[rev], mu[rev]), rev = N-2 .. 0   (lam:399), descending abscissae
         double term = 0;
         if (tid <= N - 3) {
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
             term = (x1 - x0) * (s_sfc[k1] * x1 + s_sfc[k0] * x0) / 2;
         }
         const double S = block_sum(term, s_red);
-        Bv = -2 * d.rho * S;
+        Bv = (d.surface == SOSRT_SURFACE_LAMBERTIAN_README ? 2 : -2) * d.rho * S;      // lam:399 as coded (negative), or README.md:215
     }
 
     // =============================== upward ===============================

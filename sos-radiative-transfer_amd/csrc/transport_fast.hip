@@ -223,7 +223,7 @@ __global__ __launch_bounds__(MAXT) void k_transport_fast(TransportArgs a) {
     }
     if (surface == SOSRT_SURFACE_SPECULAR) {
         Bv = valid ? rho * s_sfc[N - 1 - tid] : 0.0;                // spec:397
-    } else if (surface == SOSRT_SURFACE_LAMBERTIAN) {
+    } else if (surface == SOSRT_SURFACE_LAMBERTIAN || surface == SOSRT_SURFACE_LAMBERTIAN_README) {
         // -2 rho trapz(In[L-1, rev] mu[rev], mu[rev]), rev = N-2 .. 0   (lam:399), descending abscissae
         double term = 0;
         if (tid <= N - 3) {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(MAXT) void k_transport_fast(TransportArgs a) {
         __syncthreads();
         double S = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) S += s_red[i];
-        Bv = -2 * rho * S;
+        Bv = (surface == SOSRT_SURFACE_LAMBERTIAN_README ? 2 : -2) * rho * S;          // lam:399 as coded (negative), or README.md:215
     }
 
     stamp(3);

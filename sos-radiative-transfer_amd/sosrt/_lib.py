@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SOSRT_LIB") or os.path.join(os.path.dirname(_HERE), "
 SOSRT_OK, E_INVALID, E_HIP, E_STATE, E_NOMEM = 0, -1, -2, -3, -4
 COL_OK, COL_INDEXERROR, COL_MAXORDERS = 0, 1, 2
 GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
-SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN = 0, 1, 2
+SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN, SURFACE_LAMBERTIAN_README = 0, 1, 2, 3
 K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU = 0, 1, 2, 3
 PHASE_ISO, PHASE_RAYLEIGH, PHASE_HG, PHASE_TABLE = 0, 1, 2, 3
 
@@ -45,6 +45,10 @@ SIGNATURES = {
     "sosrt_phase_p0_dev": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "sosrt_phase_p0": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "sosrt_phase_matrix": (c_int, [c_void_p, c_int, c_double, c_void_p]),
+    "sosrt_comm_unique_id": (c_int, [c_void_p]),
+    "sosrt_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "sosrt_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "sosrt_comm_destroy": (c_int, [c_void_p]),
     "sosrt_limit_mu_down": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sosrt_asymptotic_down": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sosrt_plan_weights": (c_int, [c_void_p, c_void_p]),

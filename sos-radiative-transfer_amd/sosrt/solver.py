@@ -101,9 +101,12 @@ class Solver:
                     surface="specular"):
         """Three-zone columns (spec:23-53).  Scalars broadcast over the batch."""
         B = int(np.size(idx_up))
-        sf = {"specular": _lib.SURFACE_SPECULAR, "lambertian": _lib.SURFACE_LAMBERTIAN}.get(surface)
+        # 'lambertian' is the reference's file as coded (lam:399/401: negative reflected radiance, SURVEY H2);
+        # 'lambertian_readme' the same term with the sign of the reference's README.md:215
+        sf = {"specular": _lib.SURFACE_SPECULAR, "lambertian": _lib.SURFACE_LAMBERTIAN,
+              "lambertian_readme": _lib.SURFACE_LAMBERTIAN_README}.get(surface)
         if sf is None:
-            raise ValueError("surface must be 'specular' or 'lambertian', got %r" % (surface,))
+            raise ValueError("surface must be 'specular', 'lambertian' or 'lambertian_readme', got %r" % (surface,))
         iu = _i32(np.reshape(idx_up, (B,)), B, "idx_up")
         idn = _i32(np.reshape(idx_down, (B,)), B, "idx_down")
         v = [_vec(x, B, n) for x, n in ((mu0, "mu0"), (grd_alb, "grd_alb"), (alb_atm, "alb_atm"), (alb_aer, "alb_aer"),
@@ -245,6 +248,26 @@ class Solver:
         out = np.empty((self.D, self.D))
         check(lib().sosrt_phase_matrix(self._h, self._KINDS[kind], float(g), _ptr(out)))
         return out
+
+    # ---- multi-GPU gather over RCCL (one process per GPU) -------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL id, made by one rank and handed to the others by any means."""
+        buf = ctypes.create_string_buffer(128)
+        check(lib().sosrt_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        check(lib().sosrt_comm_init(self._h, int(rank), int(world), ctypes.c_char_p(unique_id)))
+
+    def gather_device(self, root: int, counts, d_send: int, d_recv: int):
+        """counts[world] doubles per rank; d_send / d_recv device addresses; enqueued on the handle's stream."""
+        c = np.ascontiguousarray(counts, dtype=np.int64)
+        check(lib().sosrt_gather(self._h, int(root), _ptr(c), ctypes.c_void_p(d_send) if d_send else None,
+                                 ctypes.c_void_p(d_recv) if d_recv else None))
+
+    def comm_destroy(self):
+        check(lib().sosrt_comm_destroy(self._h))
 
     # ---- helper level ----------------------------------------------------------
     def limit_mu_down(self, rows, idx):

@@ -80,7 +80,12 @@ def test_helpers_match_reference():
         N, idx = (int(x) for x in d["l%d_Nidx" % i])
         row, mud = d["l%d_row" % i], np.linspace(-1, 0, N)
         v = np.array([In_limit.improved_limit_mu_down(row, mud, N, idx, k) for k in range(idx)])
-        assert_close(v, d["l%d_vals" % i], 1e-10 if N <= 256 else 5e-9, "improved_limit_mu_down N=%d idx=%d" % (N, idx))
+        # 1e-10 of the radiance the values are extrapolated from: these rows carry 10 % noise, which an extrapolation over
+        # idx grid steps amplifies (|coefficients| up to 150 at N = 501) -- for the reference's np.polyfit as for the table
+        src = np.max(np.abs(row[-(idx + 5):-idx]))
+        assert np.max(np.abs(v - d["l%d_vals" % i])) <= RTOL * src, "improved_limit_mu_down N=%d idx=%d" % (N, idx)
+        if N <= 256:
+            assert_close(v, d["l%d_vals" % i], RTOL, "improved_limit_mu_down N=%d idx=%d" % (N, idx))
         w = np.array([In_limit.limit_mu_down(row, mud, N, idx, k) for k in range(idx)])
         assert np.array_equal(w, d["l%d_lin" % i])
     for N, m1, m2 in d["mu_approx"]:
@@ -189,7 +194,8 @@ def test_SOS_Aer_call_surface():
 # ----------------------------------------------------------------------------------------------
 # seeded batches against the oracle (ragged convergence, every surface, every idx bucket)
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,N,surface", [(40, 32, "specular"), (36, 64, "lambertian"), (30, 100, "specular")])
+@pytest.mark.parametrize("L,N,surface", [(40, 32, "specular"), (36, 64, "lambertian"), (30, 100, "specular"),
+                                         (36, 64, "lambertian_readme")])
 def test_seeded_batch_matches_oracle(L, N, surface, transport_mode):
     rng = np.random.default_rng(1000 + N)
     B = 6
@@ -215,7 +221,9 @@ def test_seeded_batch_matches_oracle(L, N, surface, transport_mode):
             continue
         assert r.status[b] == _lib.COL_OK, b
         assert r.n[b] == ref.n, (b, r.n[b], ref.n)
-        assert_close(r.I[b], ref.I, RTOL if surface == "specular" else 1e-9, "column %d" % b)
+        # 'lambertian' as the reference codes it reflects NEGATIVE radiance: successive orders alternate in
+        # sign and their sum cancels, which amplifies the rounding of either implementation relative to |I|
+        assert_close(r.I[b], ref.I, 1e-9 if surface == "lambertian" else RTOL, "column %d" % b)
 
 
 # ----------------------------------------------------------------------------------------------

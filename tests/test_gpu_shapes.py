@@ -267,3 +267,47 @@ def test_sharded_solve_equals_single_rank_bit_for_bit():
     # and the same holds for a sub-batch solved on its own (different tilings of the contraction)
     sub = SOS_Aer_batch(mu0[:5], taer[:5], rho[:5], **kw)
     assert np.array_equal(sub.I, one.I[:5])
+
+
+def test_reference_shipped_size_L800_N501():
+    """The size the reference ships (spec:33,57: nb_layers = 800, nb_angles = 501 -- odd and > 256, so the
+    register-streaming transport kernel and the N >= 501 extrapolation tables) against the oracle, one column, at
+    the north-star tolerance."""
+    L, N = 800, 501
+    mu = inputs.direction_grid(N)
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, 0.5)
+    P0r, Pr = inputs.phase_function("hg", N, mu, 0.5, 0.7)
+    r = SOS_Aer_batch([0.5], [0.120], [0.3], tauStar_atm=0.104, alb_atm=1.0, alb_aer=1.0, nb_layers=L, nb_angles=N,
+                      P_atm=Pa, P_aer=Pr, P0_atm=P0a[None], P0_aer=P0r[None], max_orders=64)
+    c = O.make_column(0.5, 120, 25, 17, L, 0.104, 0.120, 0.3, 1.0, 1.0, N, P0a, Pa, P0r, Pr)
+    ref = O.solve_column(c, literal=False)
+    assert int(r.n[0]) == ref.n and int(r.status[0]) == 0
+    assert_close(r.I[0], ref.I, RTOL, "I at the shipped size")
+    # SOS_Aer(): the per-order history has n entries, not max_orders of them (1.6 GB per column otherwise)
+    from sosrt.main import SOS_Aer
+    one = SOS_Aer(nb_layers=L, nb_angles=N, grd_alb=0.3, P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, max_orders=256)
+    assert one.I_saved.shape == (ref.n, L, 2 * N) and one.n == ref.n
+    assert_close(one.I_saved.sum(axis=0), one.I, 1e-13, "sum of the orders")
+
+
+def test_rccl_entry_points_world_of_one():
+    """sosrt_comm_unique_id / sosrt_comm_init / sosrt_gather / sosrt_comm_destroy: RCCL bound at run time.  One GPU
+    here, so a communicator of one rank; the driver's multi-GPU runs use torch.distributed over the same RCCL."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    s = Solver(8, 8, max_batch=2, max_orders=2)
+    s.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    uid = Solver.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    s.comm_init(0, 1, uid)
+    with pytest.raises(_lib.SosrtError):
+        s.comm_init(0, 1, uid)                       # one communicator per handle
+    x = torch.arange(1000, dtype=torch.float64, device=dev) * 0.5
+    y = torch.zeros(1000, dtype=torch.float64, device=dev)
+    s.gather_device(0, [1000], x.data_ptr(), y.data_ptr())
+    s.synchronize()
+    assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        s.gather_device(3, [1000], x.data_ptr(), y.data_ptr())
+    s.comm_destroy()
+    s.close()

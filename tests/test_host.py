@@ -49,8 +49,13 @@ def test_plan_tables(N):
         s0, ns, C = s.plan_fix_table(idx)
         ref = np.array([O.improved_limit_mu_down(row, mu[:N], N, idx, i) for i in range(idx)])
         got = C @ row[s0:s0 + ns]
-        # np.polyfit's own rounding grows with N and idx
-        assert_close(got[::-1], ref[::-1], 1e-10 if N <= 256 else 5e-9, "fix table N=%d idx=%d" % (N, idx))
+        # 1e-10 of the radiance the values are extrapolated from (the row carries 10 % noise, which an extrapolation over
+        # idx grid steps amplifies for the reference's np.polyfit and for the table alike) ...
+        assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(row[s0:s0 + ns])), "fix table N=%d idx=%d" % (N, idx)
+        # ... and element-wise 1e-10 on a smooth row, the shape of a radiance field next to mu = 0
+        smooth = np.exp(-0.3 / np.maximum(-mu[:N], 1e-3))
+        ref_s = np.array([O.improved_limit_mu_down(smooth, mu[:N], N, idx, i) for i in range(idx)])
+        assert_close(C @ smooth[s0:s0 + ns], ref_s, 1e-10, "fix table, smooth row, N=%d idx=%d" % (N, idx))
     s.close()
 
 
@@ -144,3 +149,4 @@ def test_mie_series_and_log_normal_ensemble():
         assert (P > 0).all() and (P0 > 0).all()
     P0e, _ = inputs.phase_function("eva", N, mug, 0.5)
     assert P0e[:N].sum() > 2 * P0e[N:].sum()        # micron-size sulphate scatters forward: sunlight keeps going down
+
