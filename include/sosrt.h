@@ -80,6 +80,16 @@ int sosrt_set_grid(sosrt_t* h, const double* mu);
  * single-slab geometry.  Folded on the host into W[k][m] = w_k P[m][2N-1-k] (I1_In:73, spec:321). */
 int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer);
 
+/* arithmetic of the source-function contraction (BASELINE configs[4]: "fp64 -> fp32 mixed with tolerance study").
+ * SOSRT_CONTRACT_F64 (default): v_mfma_f64_16x16x4_f64 -- the only mode that meets the 1e-10 parity bar.
+ * SOSRT_CONTRACT_F32: operands rounded to float, v_mfma_f32_16x16x4_f32 with a float accumulator; transport, running
+ * total and convergence test stay fp64.  About 3e-7 of the field maximum away from the fp64 result (measured on the
+ * device: profiles/r02_mixed_precision_gpu.txt) -- an opt-in for callers with that tolerance, never the default.
+ * Needs at most 32 distinct slab coefficient pairs in the batch. */
+#define SOSRT_CONTRACT_F64 0
+#define SOSRT_CONTRACT_F32 1
+int sosrt_set_contraction(sosrt_t* h, int mode);
+
 /* per-column scalars (the locals of spec:23-53).  Arrays have B entries.
  *   THREE_ZONE : idx_up, idx_down (spec:40), mu0, grd_alb, alb_atm, alb_aer, dtau_atm, dtau_aer
  *                (spec:50-53), tauStar_tot (spec:36).

@@ -101,6 +101,10 @@ struct sosrt_handle {
     double *d_Wmix = nullptr, *d_mixca = nullptr, *d_mixcr = nullptr;
     int* d_mixgroup = nullptr;
     int* d_slabtilegroup = nullptr;      // [tiles] group of every 32-row slab tile of the dense contraction
+    int contraction = SOSRT_CONTRACT_F64;
+    float *d_Wa32 = nullptr, *d_Wmix32 = nullptr;   // float copies of W_atm and of the combined slab matrices (SOSRT_CONTRACT_F32)
+    size_t mix32_capacity = 0;
+    bool w32_dirty = true;
     int* d_livelist = nullptr;           // [max_batch] live columns of the current order, written by the source-function launch
     size_t mix_capacity = 0;
     // device: fields (internal)
@@ -235,6 +239,22 @@ ColScalars scalars_of(sosrt_handle* h) {
     return sc;
 }
 
+// buffers of the float contraction (SOSRT_CONTRACT_F32)
+int ensure_w32(sosrt_handle* h) {
+    if (h->contraction != SOSRT_CONTRACT_F32) return 0;
+    if (h->nslab > 0 && h->mix_groups == 0)
+        return fail(SOSRT_E_INVALID, "the float contraction needs at most %d distinct slab coefficient pairs in a batch", sosrt_handle::kMaxMixGroups);
+    const size_t need = (size_t)h->g.Dp * h->g.Wld * (size_t)(h->mix_groups > 0 ? h->mix_groups : 1);
+    if (need > h->mix32_capacity) {
+        if (h->d_Wmix32) hipFree(h->d_Wmix32);
+        h->d_Wmix32 = nullptr; h->mix32_capacity = 0;
+        if (int e = dalloc(&h->d_Wmix32, need)) return e;
+        h->mix32_capacity = need;
+        h->w32_dirty = true;
+    }
+    return 0;
+}
+
 // Jn for every row of a column group (grp < 0: the whole batch) in one launch: plain rows against W_atm, slab rows
 // against the combined matrix of their coefficient pair (or W_atm and W_aer in two passes)
 void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0,
@@ -269,6 +289,21 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
             h->mix_dirty = false;
         }
         ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; ga.slab_tile_group = h->d_slabtilegroup + h->slab_off[g0] / 32;
+    }
+    if (h->contraction == SOSRT_CONTRACT_F32) {
+        // float operands, float accumulator: the dense tiling over the row lists for every order (tiles of converged
+        // columns leave at once)
+        if (h->w32_dirty) {
+            prof_break(h);
+            const size_t per = (size_t)h->g.Dp * h->g.Wld;
+            launch_to_float(s, per, h->d_Wa, h->d_Wa32);
+            if (h->mix_groups > 0) launch_to_float(s, per * h->mix_groups, h->d_Wmix, h->d_Wmix32);
+            h->w32_dirty = false;
+        }
+        prof_begin(h, SOSRT_K_GEMM, pg);
+        launch_gemm_f32(s, ga, h->d_Wa32, h->d_Wmix32);
+        prof_end(h, SOSRT_K_GEMM, pg);
+        return;
     }
     prof_begin(h, SOSRT_K_GEMM, pg);
     if (tail_cols > 0 && active && h->nslab >= 0) {
@@ -398,7 +433,7 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist};
+                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -424,6 +459,19 @@ int sosrt_set_saved_orders(sosrt_t* h, int slots) {
     if (!h) return fail(SOSRT_E_INVALID, "null handle");
     if (slots < 1 || slots > h->max_orders) return fail(SOSRT_E_INVALID, "slots must be in 1..max_orders=%d (got %d)", h->max_orders, slots);
     h->saved_slots = slots;
+    return 0;
+}
+
+int sosrt_set_contraction(sosrt_t* h, int mode) {
+    if (int e = need_gpu(h)) return e;
+    if (mode != SOSRT_CONTRACT_F64 && mode != SOSRT_CONTRACT_F32) return fail(SOSRT_E_INVALID, "unknown contraction mode %d", mode);
+    if (mode == SOSRT_CONTRACT_F32) {
+        HIPCHK(hipSetDevice(h->device));
+        const size_t per = (size_t)h->g.Dp * h->g.Wld;
+        if (!h->d_Wa32) { if (int e = dalloc(&h->d_Wa32, per)) return e; }
+        h->w32_dirty = true;
+    }
+    h->contraction = mode;
     return 0;
 }
 
@@ -489,6 +537,7 @@ int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer) {
     else h->Wr_h.clear();
     h->have_phase = true;
     h->mix_dirty = true;
+    h->w32_dirty = true;
     if (h->gpu) {
         HIPCHK(hipSetDevice(h->device));
         const Grid& g = h->g;
@@ -571,6 +620,7 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
     }
     h->mix_groups = 0;
     h->mix_dirty = true;
+    h->w32_dirty = true;
     if (geometry == SOSRT_GEOM_THREE_ZONE && h->nslab > 0) {
         // distinct slab coefficient pairs (spec:321: (w_atm/4) f_atm on W_atm, (w_aer/4) f_aer on W_aer)
         std::vector<double> gca, gcr;
@@ -652,6 +702,7 @@ int sosrt_source(sosrt_t* h, int B, const double* In_1, double* Jn_out) {
     if (int e = check_ready(h, B, true)) return e;
     if (!In_1 || !Jn_out) return fail(SOSRT_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->device));
+    if (int e = ensure_w32(h)) return e;
     const size_t n = (size_t)B * h->L * h->D;
     HIPCHK(hipMemcpyAsync(h->d_InA, In_1, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     // the row coefficients depend on tau only through the zone bounds; prepare needs a tau buffer
@@ -734,6 +785,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     if (!d_I1_in && h->geom == SOSRT_GEOM_THREE_ZONE && !d_P0_aer) return fail(SOSRT_E_INVALID, "three-zone geometry needs P0_aer");
     if (h->max_orders >= 65536) return fail(SOSRT_E_INVALID, "max_orders must be < 65536");
     HIPCHK(hipSetDevice(h->device));
+    if (int e = ensure_w32(h)) return e;
     hipStream_t s = h->stream;
     const Grid& g = h->g;
     const size_t LD = (size_t)h->L * h->D;
@@ -826,7 +878,8 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             hipStream_t sg = group_stream(h, k);
             const size_t fo = (size_t)q.b0 * LD;
             // this launch also publishes the group's live count after order n-1
-            const int tail_cols = (q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
+            // (the float contraction has the dense tiling only: no live list for the transport either)
+            const int tail_cols = (h->contraction == SOSRT_CONTRACT_F64 && q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
             run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway

@@ -165,6 +165,9 @@ __device__ inline void publish_live(const GemmArgs& g) {
     }
 }
 void launch_gemm(hipStream_t s, const GemmArgs& a);
+// jn_gemm_f32.hip: the contraction with float operands and a float accumulator (opt-in, tolerance study)
+void launch_gemm_f32(hipStream_t s, const GemmArgs& a, const float* Wa32, const float* Wmix32);
+void launch_to_float(hipStream_t s, size_t n, const double* src, float* dst);
 void launch_wmix(hipStream_t s, size_t n, int ngroups, const double* Wa, const double* Wr, const double* ca, const double* cr,
                  double* Wmix);
 // some columns have converged (at most `cols` are live, an upper bound): workgroups only for live

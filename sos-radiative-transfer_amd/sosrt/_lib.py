@@ -15,6 +15,7 @@ COL_OK, COL_INDEXERROR, COL_MAXORDERS = 0, 1, 2
 GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
 SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN, SURFACE_LAMBERTIAN_README = 0, 1, 2, 3
 K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU = 0, 1, 2, 3
+CONTRACT_F64, CONTRACT_F32 = 0, 1
 PHASE_ISO, PHASE_RAYLEIGH, PHASE_HG, PHASE_TABLE = 0, 1, 2, 3
 
 _dp = POINTER(c_double)
@@ -29,6 +30,7 @@ SIGNATURES = {
     "sosrt_set_stream": (c_int, [c_void_p, c_void_p]),
     "sosrt_synchronize": (c_int, [c_void_p]),
     "sosrt_set_saved_orders": (c_int, [c_void_p, c_int]),
+    "sosrt_set_contraction": (c_int, [c_void_p, c_int]),
     "sosrt_set_grid": (c_int, [c_void_p, c_void_p]),
     "sosrt_set_phase": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sosrt_set_columns": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 9),

@@ -74,6 +74,14 @@ class Solver:
     def synchronize(self):
         check(lib().sosrt_synchronize(self._h))
 
+    def set_contraction(self, mode="f64"):
+        """'f64' (default, the parity path) | 'f32' (float operands and accumulator in the Jn contraction: opt-in,
+        about 3e-7 away from the fp64 result; BASELINE configs[4])."""
+        m = {"f64": _lib.CONTRACT_F64, "f32": _lib.CONTRACT_F32}.get(mode)
+        if m is None:
+            raise ValueError("contraction must be 'f64' or 'f32'")
+        check(lib().sosrt_set_contraction(self._h, m))
+
     def set_grid(self, mu):
         mu = _f64(mu, (self.D,), "mu")
         check(lib().sosrt_set_grid(self._h, _ptr(mu)))

@@ -311,3 +311,30 @@ def test_rccl_entry_points_world_of_one():
         s.gather_device(3, [1000], x.data_ptr(), y.data_ptr())
     s.comm_destroy()
     s.close()
+
+
+def test_float_contraction_is_an_opt_in_that_misses_the_parity_bar():
+    """BASELINE configs[4] (fp64 -> fp32 mixed with tolerance study) on the device: the float contraction runs, gives the
+    same order counts on this sweep, and lands 1e-8 .. 1e-5 away from the fp64 result -- outside the 1e-10 bar, which
+    is why it is not the default."""
+    import io
+    import study_mixed_precision_gpu as S
+    r = S.study(64, 60, 64, out=io.StringIO(), steps=1)
+    # typical element 1e-8 .. 1e-5 away; isolated rows further, where the perturbation moves a data-dependent search (spec:403-406)
+    assert 1e-9 < r["med"] < 1e-5 and 1e-9 < r["p999"] < 1e-3 and r["rel"] > 1e-10
+    # and the step-level entry point follows the mode
+    N, L = 32, 20
+    mu = inputs.direction_grid(N)
+    P = inputs.phase_function("hg", N, mu, 0.5, 0.6)[1]
+    s = Solver(L, N, max_batch=2, max_orders=4)
+    s.set_grid(mu); s.set_phase(P)
+    s.set_columns_single_slab([0.5, 0.7], 0.9, 0.3)
+    x = np.random.default_rng(0).uniform(0.1, 1.0, (2, L, 2 * N))
+    j64 = s.source(x)
+    s.set_contraction("f32")
+    j32 = s.source(x)
+    s.set_contraction("f64")
+    assert np.array_equal(s.source(x), j64)
+    e = np.max(np.abs(j32 - j64)) / np.max(np.abs(j64))
+    assert 1e-9 < e < 1e-5
+    s.close()
