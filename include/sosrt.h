@@ -102,6 +102,20 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface,
                       const double* dtau_atm, const double* dtau_aer,
                       const double* tauStar_tot);
 
+/* The same with a caller's ZONE TABLE instead of one slab: zones top to bottom, zone z of column b starts at
+ * row zone_r0[b][z] (zone_r0[b][0] = 0, ascending) and ends before the next one; zone_mix[b][z] = 1 marks an aerosol zone
+ * with single-scattering albedo zone_alb_aer[b][z] and optical-depth step zone_dtau_aer[b][z] (the dtau_aer of spec:52,
+ * i.e. the slab's aerosol optical depth / its number of rows), 0 a clear zone (its two aerosol entries are ignored).
+ * Aerosol zones are separated and bounded by clear ones; at most SOSRT_MAX_ZONES zones (four slabs).  Arrays are
+ * [B][nzmax] row-major; nz[b] <= nzmax zones are read for column b.  Every formula of the path is evaluated per zone
+ * exactly as the reference writes it for its three (spec:113-449); the extrapolation bucket (spec:342,361,380) of a clear
+ * zone below a slab follows that slab's last row.  (clear, slab, clear) columns give bit-for-bit the results of
+ * sosrt_set_columns.  The optical-depth grid tau of the solve must be consistent with the table (taup:21-27 per slab). */
+#define SOSRT_MAX_ZONES 8
+int sosrt_set_columns_zones(sosrt_t* h, int B, int surface, int nzmax, const int* nz, const int* zone_r0, const int* zone_mix,
+                            const double* mu0, const double* grd_alb, const double* alb_atm, const double* dtau_atm,
+                            const double* zone_alb_aer, const double* zone_dtau_aer, const double* tauStar_tot);
+
 /* ---- step level (host pointers): parity surface of SOS_Aer_I1_In.py ------------------------- */
 /* I1_NumInt (I1_In:13) / three-zone first order (spec:104-292).
  * tau [B][L], P0_atm / P0_aer [B][2N] (P0_aer may be NULL for SINGLE_SLAB), I1 out [B][L][2N] */

@@ -67,6 +67,24 @@ def tau_profile(tauStar_atm, tauStar_aer, z0, z_up, z_down, L) -> np.ndarray:
     return tau
 
 
+def tau_profile_slabs(tauStar_atm, slabs, z0, L):
+    """taup:15-27 with several aerosol layers: `slabs` = [(z_up, z_down, tauStar_aer), ...] from the top down, each a
+    linear ramp of its aerosol optical depth over its rows on top of the uniform molecular profile.  Returns
+    (tau, [(idx_up, idx_down), ...]).  One slab gives tau_profile()."""
+    z = np.linspace(z0, 0, L)
+    tau = np.arange(0, L) * tauStar_atm / (L - 1)
+    rows = []
+    for z_up, z_down, t_aer in slabs:
+        if z_down > z_up:
+            z_down, z_up = z_up, z_down
+        iu, idn = int(np.argmin(np.abs(z - z_up))), int(np.argmin(np.abs(z - z_down)))
+        d_aer = t_aer / (idn + 1 - iu)
+        for i in range(iu, L):
+            tau[i] += (i + 1 - iu) * d_aer if i <= idn else t_aer
+        rows.append((iu, idn))
+    return tau, rows
+
+
 def mu_approx_In(mu, N):
     """In_limit:145-153 (result is unused by the reference's transport)."""
     i = N
@@ -197,6 +215,8 @@ class _Zone:
     r0: int
     r1: int
     kind: str  # 'atm' | 'mix'
+    alb_aer: float = 0.0       # an aerosol zone's own single-scattering albedo and optical-depth step (zone tables)
+    dtau_aer: float = 0.0
 
 
 @dataclass
@@ -218,12 +238,19 @@ class Column:
     P_atm: np.ndarray
     P0_aer: np.ndarray
     P_aer: np.ndarray
-    surface: str = "specular"      # 'specular' | 'lambertian' (coded sign of lam:399/401)
+    surface: str = "specular"      # 'specular' | 'lambertian' (coded sign of lam:399/401) | 'lambertian_readme'
+    # Generalisation beyond the reference: an explicit zone table, clear and aerosol zones alternating,
+    # each aerosol zone with its own albedo and optical-depth step.  None = the reference's three zones.  The reference
+    # has one slab only, so more than one is PARITY UNPINNED by construction; with the three zones of the reference the
+    # table path is the same arithmetic (checked bit for bit in tests/test_oracle_golden.py).
+    zone_table: Optional[List[_Zone]] = None
 
     @property
     def zones(self) -> List[_Zone]:
+        if self.zone_table is not None:
+            return self.zone_table
         L = len(self.tau)
-        return [_Zone(0, self.idx_up - 1, "atm"), _Zone(self.idx_up, self.idx_down, "mix"),
+        return [_Zone(0, self.idx_up - 1, "atm"), _Zone(self.idx_up, self.idx_down, "mix", self.alb_aer, self.dtau_aer),
                 _Zone(self.idx_down + 1, L - 1, "atm")]
 
     @property
@@ -233,6 +260,16 @@ class Column:
     @property
     def f_aer(self):
         return self.dtau_aer / (self.dtau_atm + self.dtau_aer)
+
+    def zone_fractions(self, z: _Zone):
+        """(f_atm, f_aer) of an aerosol zone, spec:149."""
+        return self.dtau_atm / (self.dtau_atm + z.dtau_aer), z.dtau_aer / (self.dtau_atm + z.dtau_aer)
+
+    def tau_ref(self) -> List[float]:
+        """tau_ref of every zone (spec:342,361,380): the zone's own last row for the top zone and for a slab, the last row
+        of the slab above for a clear zone below one."""
+        zs = self.zones
+        return [self.tau[z.r1] if (i == 0 or z.kind == "mix") else self.tau[z.r0 - 1] for i, z in enumerate(zs)]
 
 
 def make_column(mu0, z0, z_up, z_down, nb_layers, tauStar_atm, tauStar_aer, grd_alb, alb_atm, alb_aer,
@@ -249,6 +286,25 @@ def make_column(mu0, z0, z_up, z_down, nb_layers, tauStar_atm, tauStar_aer, grd_
                   P0_atm=P0_atm, P_atm=P_atm, P0_aer=P0_aer, P_aer=P_aer, surface=surface)
 
 
+def make_column_slabs(mu0, z0, slabs, nb_layers, tauStar_atm, grd_alb, alb_atm, nb_angles, P0_atm, P_atm, P0_aer, P_aer,
+                      surface="specular") -> Column:
+    """A column with several aerosol layers: `slabs` = [(z_up, z_down, tauStar_aer, alb_aer), ...] from the top down."""
+    tau, rows = tau_profile_slabs(tauStar_atm, [s[:3] for s in slabs], z0, nb_layers)
+    zt, prev = [], 0
+    for (iu, idn), sl in zip(rows, slabs):
+        assert iu > prev and idn >= iu, "slabs must be separated by clear rows"
+        zt.append(_Zone(prev, iu - 1, "atm"))
+        zt.append(_Zone(iu, idn, "mix", sl[3], sl[2] / (idn + 1 - iu)))
+        prev = idn + 1
+    assert prev <= nb_layers - 1
+    zt.append(_Zone(prev, nb_layers - 1, "atm"))
+    t_aer = sum(s[2] for s in slabs)
+    return Column(tau=tau, mu=make_mu(nb_angles), N=nb_angles, idx_up=rows[0][0], idx_down=rows[0][1], mu0=mu0, grd_alb=grd_alb,
+                  alb_atm=alb_atm, alb_aer=slabs[0][3], dtau_atm=tauStar_atm / nb_layers, dtau_aer=zt[1].dtau_aer,
+                  tauStar_tot=tauStar_atm + t_aer, P0_atm=P0_atm, P_atm=P_atm, P0_aer=P0_aer, P_aer=P_aer, surface=surface,
+                  zone_table=zt)
+
+
 def first_order(c: Column) -> np.ndarray:
     """Three-zone first order with the specularly reflected beam, spec:104-292."""
     tau, mu, N, mu0 = c.tau, c.mu, c.N, c.mu0
@@ -257,7 +313,12 @@ def first_order(c: Column) -> np.ndarray:
     T = c.tauStar_tot
     R = F0 * c.grd_alb * np.exp(-T / mu0)
     q_atm = c.alb_atm * c.P0_atm / (4 * np.pi)
-    q_mix = (c.alb_atm * c.P0_atm * c.f_atm + c.alb_aer * c.P0_aer * c.f_aer) / (4 * np.pi)
+
+    def q_of(z):
+        if z.kind != "mix":
+            return q_atm
+        fa, fr = c.zone_fractions(z)
+        return (c.alb_atm * c.P0_atm * fa + z.alb_aer * c.P0_aer * fr) / (4 * np.pi)
     mirror = 2 * N - 1 - np.arange(2 * N)
     I1 = np.zeros((L, 2 * N))
     zones = c.zones
@@ -266,7 +327,7 @@ def first_order(c: Column) -> np.ndarray:
         md = mu[:N - 1]
         near = np.abs(md + mu0) < 0.0001
         for zi, z in enumerate(zones):
-            q = q_mix if z.kind == "mix" else q_atm
+            q = q_of(z)
             qd, qdm = q[:N - 1], q[mirror[:N - 1]]
             if zi == 0:
                 t_bd = t_bs = 0.0
@@ -285,7 +346,7 @@ def first_order(c: Column) -> np.ndarray:
         near = np.abs(mp - mu0) < 0.0001
         for zi in range(len(zones) - 1, -1, -1):
             z = zones[zi]
-            q = q_mix if z.kind == "mix" else q_atm
+            q = q_of(z)
             qu, qum = q[N + 1:], q[mirror[N + 1:]]
             bottom = zi == len(zones) - 1
             if bottom:
@@ -311,12 +372,14 @@ def source_function(c: Column, In_1: np.ndarray) -> np.ndarray:
     L = len(c.tau)
     Jn = np.zeros((L, 2 * c.N))
     Pa, Pr = c.P_atm[:, ::-1], c.P_aer[:, ::-1]
-    for t in range(L):
-        if c.idx_up <= t <= c.idx_down:
-            Jn[t, :] = (c.alb_atm / 4) * _trapz(Pa * In_1[t, :], c.mu, axis=1) * c.f_atm \
-                + (c.alb_aer / 4) * _trapz(Pr * In_1[t, :], c.mu, axis=1) * c.f_aer
-        else:
-            Jn[t, :] = (c.alb_atm / 4) * _trapz(Pa * In_1[t, :], c.mu, axis=1)
+    for z in c.zones:
+        for t in range(z.r0, z.r1 + 1):
+            if z.kind == "mix":
+                fa, fr = c.zone_fractions(z)
+                Jn[t, :] = (c.alb_atm / 4) * _trapz(Pa * In_1[t, :], c.mu, axis=1) * fa \
+                    + (z.alb_aer / 4) * _trapz(Pr * In_1[t, :], c.mu, axis=1) * fr
+            else:
+                Jn[t, :] = (c.alb_atm / 4) * _trapz(Pa * In_1[t, :], c.mu, axis=1)
     return Jn
 
 
@@ -388,7 +451,7 @@ def transport(c: Column, Jn: np.ndarray, literal: bool = True) -> np.ndarray:
     """One order of three-zone transport for a column (spec:326-449)."""
     tau = c.tau
     L = len(tau)
-    tref = [tau[c.idx_up - 1], tau[c.idx_down], tau[c.idx_down]]   # spec:342,361,380
+    tref = c.tau_ref()                                             # spec:342,361,380
     return _transport(Jn, tau, c.mu, c.N, c.zones, tref, thick_test=tau[L - 1] / c.mu[c.N + 1],
                       surface=c.surface, grd_alb=c.grd_alb, literal=literal)
 
@@ -484,7 +547,7 @@ def net_flux(I, mu, tau, N, mu0, grd_alb):
                      for i in range(L)])
 
 
-def heating_rate(I, mu, tau, N, mu0, grd_alb, z_profile, idx_up, idx_down):
+def heating_rate(I, mu, tau, N, mu0, grd_alb, z_profile, idx_up, idx_down, slabs=None):
     """graphe:70-91: -(1/(rho c_p)) d(flux_down + flux_up)/dz with the F0/(4 pi) beam terms, last level copied
     from the one above, and the two levels at the slab boundaries overwritten by their upper neighbours
     ('erase_pics', graphe:87-91)."""
@@ -496,8 +559,9 @@ def heating_rate(I, mu, tau, N, mu0, grd_alb, z_profile, idx_up, idx_down):
     for i in range(L - 1):
         hr[i] = -(1 / (rho * c_p)) * (flux[i + 1] - flux[i]) / (z_profile[i + 1] - z_profile[i])
     hr[-1] = hr[-2]
-    hr[idx_up - 1] = hr[idx_up - 2]
-    hr[idx_down] = hr[idx_down - 1]
+    for iu, idn in (slabs if slabs is not None else [(idx_up, idx_down)]):      # one pair per aerosol zone
+        hr[iu - 1] = hr[iu - 2]
+        hr[idn] = hr[idn - 1]
     return hr
 
 

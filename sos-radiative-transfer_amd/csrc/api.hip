@@ -87,6 +87,10 @@ struct sosrt_handle {
     int* d_small = nullptr;
     // device: columns
     int *d_idx_up = nullptr, *d_idx_down = nullptr;
+    int *d_nz = nullptr, *d_zr0 = nullptr, *d_zmix = nullptr;     // zone tables [max_batch][kMaxZones]
+    double *d_zwr = nullptr, *d_zdtr = nullptr;
+    int max_nz = 1;                      // most zones of any column: beyond three the general transport kernel runs
+    bool simple_zones = true;            // every column is (clear, slab, clear): the live-column tilings of the contraction apply
     double* d_scal = nullptr;            // 7 arrays of max_batch
     ColDesc* d_desc = nullptr;
     double *d_rca = nullptr, *d_rcr = nullptr;
@@ -233,6 +237,7 @@ ColScalars scalars_of(sosrt_handle* h) {
     ColScalars sc;
     const size_t mb = h->max_batch;
     sc.idx_up = h->d_idx_up; sc.idx_down = h->d_idx_down;
+    sc.nz = h->d_nz; sc.zr0 = h->d_zr0; sc.zmix = h->d_zmix; sc.zwr = h->d_zwr; sc.zdtr = h->d_zdtr;
     sc.mu0 = h->d_scal + 0 * mb; sc.rho = h->d_scal + 1 * mb; sc.alb_atm = h->d_scal + 2 * mb;
     sc.alb_aer = h->d_scal + 3 * mb; sc.dtau_atm = h->d_scal + 4 * mb; sc.dtau_aer = h->d_scal + 5 * mb;
     sc.T = h->d_scal + 6 * mb;
@@ -378,6 +383,11 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_small, N))) return e;
             if ((e = dalloc(&h->d_idx_up, mb))) return e;
             if ((e = dalloc(&h->d_idx_down, mb))) return e;
+            if ((e = dalloc(&h->d_nz, mb))) return e;
+            if ((e = dalloc(&h->d_zr0, mb * kMaxZones))) return e;
+            if ((e = dalloc(&h->d_zmix, mb * kMaxZones))) return e;
+            if ((e = dalloc(&h->d_zwr, mb * kMaxZones))) return e;
+            if ((e = dalloc(&h->d_zdtr, mb * kMaxZones))) return e;
             if ((e = dalloc(&h->d_scal, 7 * mb))) return e;
             if ((e = dalloc(&h->d_desc, mb))) return e;
             if ((e = dalloc(&h->d_rca, mb * L))) return e;
@@ -433,7 +443,7 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32};
+                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -550,38 +560,33 @@ int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer) {
     return 0;
 }
 
-int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* idx_up, const int* idx_down,
-                      const double* mu0, const double* grd_alb, const double* alb_atm, const double* alb_aer,
-                      const double* dtau_atm, const double* dtau_aer, const double* tauStar_tot) {
-    if (int e = need_gpu(h)) return e;
-    if (B < 1 || B > h->max_batch) return fail(SOSRT_E_INVALID, "B=%d outside 1..max_batch=%d", B, h->max_batch);
-    if (!mu0 || !alb_atm || !tauStar_tot) return fail(SOSRT_E_INVALID, "mu0, alb_atm and tauStar_tot are required");
+// Common part of sosrt_set_columns / sosrt_set_columns_zones: zone tables [B][kMaxZones] (host), per-column scalars.
+static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, const std::vector<int>& nz,
+                            const std::vector<int>& zr0, const std::vector<int>& zmix, const std::vector<double>& zwr,
+                            const std::vector<double>& zdtr, const double* mu0, const double* grd_alb, const double* alb_atm,
+                            const double* dtau_atm, const double* tauStar_tot) {
     const size_t mb = h->max_batch;
+    const int L = h->L;
     std::vector<double> sc(7 * mb, 0.0);
-    std::vector<int> slab, plain;
-    if (geometry == SOSRT_GEOM_THREE_ZONE) {
-        if (!idx_up || !idx_down || !grd_alb || !alb_aer || !dtau_atm || !dtau_aer)
-            return fail(SOSRT_E_INVALID, "three-zone geometry needs idx_up, idx_down, grd_alb, alb_aer, dtau_atm, dtau_aer");
-        if (surface != SOSRT_SURFACE_SPECULAR && surface != SOSRT_SURFACE_LAMBERTIAN && surface != SOSRT_SURFACE_LAMBERTIAN_README)
-            return fail(SOSRT_E_INVALID, "three-zone geometry needs a specular or lambertian surface");
-        for (int b = 0; b < B; ++b) {
-            if (idx_up[b] < 1 || idx_down[b] < idx_up[b] || idx_down[b] > h->L - 2)
-                return fail(SOSRT_E_INVALID, "column %d: need 1 <= idx_up <= idx_down <= nb_layers-2 (got %d, %d)", b,
-                            idx_up[b], idx_down[b]);
-        }
-    } else if (geometry == SOSRT_GEOM_SINGLE_SLAB) {
-        surface = SOSRT_SURFACE_NONE;
-    } else {
-        return fail(SOSRT_E_INVALID, "unknown geometry %d", geometry);
-    }
+    std::vector<int> slab, plain, iup(B, 0), idn(B, 0);
+    auto zone_end = [&](int b, int z) { return z + 1 < nz[b] ? zr0[b * kMaxZones + z + 1] - 1 : L - 1; };
     // column groups of the order loop: two contiguous halves for a large batch
     h->ngroups = (h->want_groups >= 2 && B >= h->split_min && B >= 2) ? 2 : 1;
     h->gb[0] = 0; h->gb[1] = h->ngroups == 2 ? B / 2 : B; h->gb[2] = B;
     for (int k = 0; k <= sosrt_handle::kMaxGroups; ++k) { h->main_off[k] = 0; h->slab_off[k] = 0; }
+    h->max_nz = 1;
+    h->simple_zones = true;                  // every column is (clear, slab, clear): the live-column tilings apply
     if (geometry == SOSRT_GEOM_THREE_ZONE) {
+        for (int b = 0; b < B; ++b) {
+            h->max_nz = nz[b] > h->max_nz ? nz[b] : h->max_nz;
+            const int* m = &zmix[b * kMaxZones];
+            if (!(nz[b] == 3 && m[0] == 0 && m[1] == 1 && m[2] == 0)) h->simple_zones = false;
+            if (nz[b] == 3) { iup[b] = zr0[b * kMaxZones + 1]; idn[b] = zr0[b * kMaxZones + 2] - 1; }
+        }
         for (int k = 0; k < h->ngroups; ++k) {
             for (int b = h->gb[k]; b < h->gb[k + 1]; ++b)
-                for (int t = 0; t < h->L; ++t) (t >= idx_up[b] && t <= idx_down[b] ? slab : plain).push_back(b * h->L + t);
+                for (int z = 0; z < nz[b]; ++z)
+                    for (int t = zr0[b * kMaxZones + z]; t <= zone_end(b, z); ++t) (zmix[b * kMaxZones + z] ? slab : plain).push_back(b * L + t);
             h->main_off[k + 1] = (int)plain.size();
             h->slab_off[k + 1] = (int)slab.size();
         }
@@ -591,16 +596,19 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
         sc[0 * mb + b] = mu0[b];
         sc[1 * mb + b] = grd_alb ? grd_alb[b] : 0.0;
         sc[2 * mb + b] = alb_atm[b];
-        sc[3 * mb + b] = alb_aer ? alb_aer[b] : 0.0;
         sc[4 * mb + b] = dtau_atm ? dtau_atm[b] : 1.0;
-        sc[5 * mb + b] = dtau_aer ? dtau_aer[b] : 0.0;
         sc[6 * mb + b] = tauStar_tot[b];
     }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->d_scal, sc.data(), 7 * mb * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (geometry == SOSRT_GEOM_THREE_ZONE) {
-        HIPCHK(hipMemcpyAsync(h->d_idx_up, idx_up, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_idx_down, idx_down, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_nz, nz.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_zr0, zr0.data(), (size_t)B * kMaxZones * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_zmix, zmix.data(), (size_t)B * kMaxZones * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_zwr, zwr.data(), (size_t)B * kMaxZones * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_zdtr, zdtr.data(), (size_t)B * kMaxZones * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_idx_up, iup.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_idx_down, idn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (!slab.empty())
             HIPCHK(hipMemcpyAsync(h->d_slabrows, slab.data(), slab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (!plain.empty())
@@ -609,33 +617,39 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
     HIPCHK(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
     h->nslab = (int)slab.size();
     h->nmain = (int)plain.size();
-    h->max_main = h->L; h->max_slab = 0;
+    h->max_main = L; h->max_slab = 0;
     if (geometry == SOSRT_GEOM_THREE_ZONE) {
         h->max_main = 0;
         for (int b = 0; b < B; ++b) {
-            const int ns = idx_down[b] - idx_up[b] + 1;
+            int ns = 0;
+            for (int z = 0; z < nz[b]; ++z)
+                if (zmix[b * kMaxZones + z]) ns += zone_end(b, z) - zr0[b * kMaxZones + z] + 1;
             h->max_slab = ns > h->max_slab ? ns : h->max_slab;
-            h->max_main = h->L - ns > h->max_main ? h->L - ns : h->max_main;
+            h->max_main = L - ns > h->max_main ? L - ns : h->max_main;
         }
     }
     h->mix_groups = 0;
     h->mix_dirty = true;
     h->w32_dirty = true;
     if (geometry == SOSRT_GEOM_THREE_ZONE && h->nslab > 0) {
-        // distinct slab coefficient pairs (spec:321: (w_atm/4) f_atm on W_atm, (w_aer/4) f_aer on W_aer)
+        // distinct slab coefficient pairs (spec:321: (w_atm/4) f_atm on W_atm, (w_aer/4) f_aer on W_aer), per (column, slab)
         std::vector<double> gca, gcr;
-        std::vector<int> gid(B);
+        std::vector<int> gid((size_t)B * kMaxZones, -1), gcol(B, 0);
         bool ok = true;
         for (int b = 0; b < B && ok; ++b) {
-            const double da = dtau_atm[b], dr = dtau_aer[b];
-            const double ca = (alb_atm[b] / 4) * (da / (da + dr)), cr = (alb_aer[b] / 4) * (dr / (da + dr));
-            int k = 0;
-            while (k < (int)gca.size() && !(gca[k] == ca && gcr[k] == cr)) ++k;
-            if (k == (int)gca.size()) {
-                if (k == sosrt_handle::kMaxMixGroups) { ok = false; break; }
-                gca.push_back(ca); gcr.push_back(cr);
+            for (int z = 0; z < nz[b] && ok; ++z) {
+                if (!zmix[b * kMaxZones + z]) continue;
+                const double da = dtau_atm[b], dr = zdtr[b * kMaxZones + z];
+                const double ca = (alb_atm[b] / 4) * (da / (da + dr)), cr = (zwr[b * kMaxZones + z] / 4) * (dr / (da + dr));
+                int k = 0;
+                while (k < (int)gca.size() && !(gca[k] == ca && gcr[k] == cr)) ++k;
+                if (k == (int)gca.size()) {
+                    if (k == sosrt_handle::kMaxMixGroups) { ok = false; break; }
+                    gca.push_back(ca); gcr.push_back(cr);
+                }
+                gid[b * kMaxZones + z] = k;
+                gcol[b] = k;                         // the live-column tilings: one slab per column
             }
-            gid[b] = k;
         }
         if (ok) {
             const size_t per = (size_t)h->g.Dp * h->g.Wld, need = per * gca.size();
@@ -648,7 +662,7 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
             if (h->mix_capacity >= need) {
                 HIPCHK(hipMemcpy(h->d_mixca, gca.data(), gca.size() * sizeof(double), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(h->d_mixcr, gcr.data(), gcr.size() * sizeof(double), hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(h->d_mixgroup, gid.data(), B * sizeof(int), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_mixgroup, gcol.data(), B * sizeof(int), hipMemcpyHostToDevice));
                 h->mix_groups = (int)gca.size();
                 // slab rows of the dense contraction listed, per column group of the order loop, coefficient pair by
                 // coefficient pair, every pair padded to whole 32-row tiles
@@ -656,8 +670,9 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
                 for (int cg = 0; cg < h->ngroups; ++cg) {
                     for (int k = 0; k < h->mix_groups; ++k) {
                         for (int b = h->gb[cg]; b < h->gb[cg + 1]; ++b)
-                            if (gid[b] == k)
-                                for (int t = idx_up[b]; t <= idx_down[b]; ++t) grouped.push_back(b * h->L + t);
+                            for (int z = 0; z < nz[b]; ++z)
+                                if (gid[b * kMaxZones + z] == k)
+                                    for (int t = zr0[b * kMaxZones + z]; t <= zone_end(b, z); ++t) grouped.push_back(b * L + t);
                         while (grouped.size() % 32) grouped.push_back(-1);
                         while (tilegroup.size() < grouped.size() / 32) tilegroup.push_back(k);
                     }
@@ -672,6 +687,70 @@ int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* i
     h->B = B; h->geom = geometry; h->surface = surface;
     h->have_cols = true;
     return 0;
+}
+
+int sosrt_set_columns(sosrt_t* h, int B, int geometry, int surface, const int* idx_up, const int* idx_down,
+                      const double* mu0, const double* grd_alb, const double* alb_atm, const double* alb_aer,
+                      const double* dtau_atm, const double* dtau_aer, const double* tauStar_tot) {
+    if (int e = need_gpu(h)) return e;
+    if (B < 1 || B > h->max_batch) return fail(SOSRT_E_INVALID, "B=%d outside 1..max_batch=%d", B, h->max_batch);
+    if (!mu0 || !alb_atm || !tauStar_tot) return fail(SOSRT_E_INVALID, "mu0, alb_atm and tauStar_tot are required");
+    std::vector<int> nz(B, 1), zr0((size_t)B * kMaxZones, 0), zmix((size_t)B * kMaxZones, 0);
+    std::vector<double> zwr((size_t)B * kMaxZones, 0.0), zdtr((size_t)B * kMaxZones, 0.0);
+    if (geometry == SOSRT_GEOM_THREE_ZONE) {
+        if (!idx_up || !idx_down || !grd_alb || !alb_aer || !dtau_atm || !dtau_aer)
+            return fail(SOSRT_E_INVALID, "three-zone geometry needs idx_up, idx_down, grd_alb, alb_aer, dtau_atm, dtau_aer");
+        if (surface != SOSRT_SURFACE_SPECULAR && surface != SOSRT_SURFACE_LAMBERTIAN && surface != SOSRT_SURFACE_LAMBERTIAN_README)
+            return fail(SOSRT_E_INVALID, "three-zone geometry needs a specular or lambertian surface");
+        for (int b = 0; b < B; ++b) {
+            if (idx_up[b] < 1 || idx_down[b] < idx_up[b] || idx_down[b] > h->L - 2)
+                return fail(SOSRT_E_INVALID, "column %d: need 1 <= idx_up <= idx_down <= nb_layers-2 (got %d, %d)", b,
+                            idx_up[b], idx_down[b]);
+            // above / inside / below the aerosol slab (spec:113-449)
+            nz[b] = 3;
+            zr0[b * kMaxZones + 1] = idx_up[b]; zr0[b * kMaxZones + 2] = idx_down[b] + 1;
+            zmix[b * kMaxZones + 1] = 1;
+            zwr[b * kMaxZones + 1] = alb_aer[b];
+            zdtr[b * kMaxZones + 1] = dtau_aer[b];
+        }
+    } else if (geometry == SOSRT_GEOM_SINGLE_SLAB) {
+        surface = SOSRT_SURFACE_NONE;
+    } else {
+        return fail(SOSRT_E_INVALID, "unknown geometry %d", geometry);
+    }
+    return set_columns_impl(h, B, geometry, surface, nz, zr0, zmix, zwr, zdtr, mu0, grd_alb, alb_atm, dtau_atm, tauStar_tot);
+}
+
+int sosrt_set_columns_zones(sosrt_t* h, int B, int surface, int nzmax, const int* nz_in, const int* zone_r0, const int* zone_mix,
+                            const double* mu0, const double* grd_alb, const double* alb_atm, const double* dtau_atm,
+                            const double* zone_alb_aer, const double* zone_dtau_aer, const double* tauStar_tot) {
+    if (int e = need_gpu(h)) return e;
+    if (B < 1 || B > h->max_batch) return fail(SOSRT_E_INVALID, "B=%d outside 1..max_batch=%d", B, h->max_batch);
+    if (!nz_in || !zone_r0 || !zone_mix || !mu0 || !grd_alb || !alb_atm || !dtau_atm || !zone_alb_aer || !zone_dtau_aer || !tauStar_tot)
+        return fail(SOSRT_E_INVALID, "null argument");
+    if (nzmax < 1 || nzmax > kMaxZones) return fail(SOSRT_E_INVALID, "nzmax must be in 1..%d (got %d)", kMaxZones, nzmax);
+    if (surface != SOSRT_SURFACE_SPECULAR && surface != SOSRT_SURFACE_LAMBERTIAN && surface != SOSRT_SURFACE_LAMBERTIAN_README)
+        return fail(SOSRT_E_INVALID, "a zone table needs a specular or lambertian surface");
+    std::vector<int> nz(B), zr0((size_t)B * kMaxZones, 0), zmix((size_t)B * kMaxZones, 0);
+    std::vector<double> zwr((size_t)B * kMaxZones, 0.0), zdtr((size_t)B * kMaxZones, 0.0);
+    for (int b = 0; b < B; ++b) {
+        nz[b] = nz_in[b];
+        if (nz[b] < 1 || nz[b] > nzmax) return fail(SOSRT_E_INVALID, "column %d: %d zones, expected 1..%d", b, nz[b], nzmax);
+        for (int z = 0; z < nz[b]; ++z) {
+            const int r0 = zone_r0[b * nzmax + z], mix = zone_mix[b * nzmax + z] != 0;
+            if (z == 0 ? r0 != 0 : !(r0 > zr0[b * kMaxZones + z - 1] && r0 < h->L))
+                return fail(SOSRT_E_INVALID, "column %d: zone %d starts at row %d (zones start at 0 and ascend, below nb_layers)", b, z, r0);
+            if (z > 0 && mix && zmix[b * kMaxZones + z - 1]) return fail(SOSRT_E_INVALID, "column %d: two adjacent aerosol zones (%d, %d): merge them", b, z - 1, z);
+            // the reference's slab lies strictly inside the column (idx_up >= 1, idx_down <= L-2, spec:40): its formulas
+            // read the rows either side of a slab
+            if (mix && (z == 0 || z == nz[b] - 1)) return fail(SOSRT_E_INVALID, "column %d: an aerosol zone must have a clear zone above and below it", b);
+            zr0[b * kMaxZones + z] = r0; zmix[b * kMaxZones + z] = mix;
+            zwr[b * kMaxZones + z] = mix ? zone_alb_aer[b * nzmax + z] : 0.0;
+            zdtr[b * kMaxZones + z] = mix ? zone_dtau_aer[b * nzmax + z] : 0.0;
+            if (mix && !(zdtr[b * kMaxZones + z] >= 0)) return fail(SOSRT_E_INVALID, "column %d zone %d: dtau_aer must be >= 0", b, z);
+        }
+    }
+    return set_columns_impl(h, B, SOSRT_GEOM_THREE_ZONE, surface, nz, zr0, zmix, zwr, zdtr, mu0, grd_alb, alb_atm, dtau_atm, tauStar_tot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -728,7 +807,7 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     launch_smallmu(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, h->d_desc, nullptr);
     prof_end(h, SOSRT_K_SMALLMU);
     prof_begin(h, SOSRT_K_TRANSPORT);
-    if (h->transport_mode >= 1 && h->fast_ok) {
+    if (h->transport_mode >= 1 && h->fast_ok && h->max_nz <= kRingZones) {
         launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E, nullptr);
         HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E,
@@ -798,7 +877,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr,
                    h->d_nactive + sosrt_handle::kMaxGroups);
     h->need_small = true;
-    const bool fast = h->transport_mode >= 1 && h->fast_ok;
+    const bool fast = h->transport_mode >= 1 && h->fast_ok && h->max_nz <= kRingZones;   // more zones: the general kernel
     const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) {
         // one attenuation table per distinct optical-depth profile
@@ -879,7 +958,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             const size_t fo = (size_t)q.b0 * LD;
             // this launch also publishes the group's live count after order n-1
             // (the float contraction has the dense tiling only: no live list for the transport either)
-            const int tail_cols = (h->contraction == SOSRT_CONTRACT_F64 && q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
+            const int tail_cols = (h->contraction == SOSRT_CONTRACT_F64 && h->simple_zones && q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
             run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway

@@ -2,7 +2,8 @@
 //
 //   k_epilogue      what the reference's callers consume from a converged field, computed where the field
 //                   lives: downward / upward flux per level (graphe:157-158, crit:380-381), diffusivity
-//                   (graphe:10), heating rate incl. the 'erase_pics' fix-up (graphe:74-91) and the net flux
+//                   (graphe:10), heating rate incl. the 'erase_pics' fix-up (graphe:74-91; at every aerosol
+//                   zone of the column's zone table) and the net flux
 //                   at the top of the atmosphere (crit:382).  One workgroup per column, one wavefront per
 //                   layer row at a time (a row of 2N doubles is read once, coalesced); the per-level net
 //                   flux stays in LDS for the finite differences of the heating rate.
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void k_epilogue(Grid g, const double* __restri
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int L = g.L, N = g.N, D = g.D;
-    extern __shared__ double s_flux[];                       // [L] flux_down + flux_up with the F0/(4 pi) beam terms
+    extern __shared__ double s_flux[];                       // [2 L]: flux_down + flux_up with the F0/(4 pi) beam terms; heating rate
     const ColDesc& d = desc[b];
     const double* tau = tau_all + (size_t)b * L;
     const double mu0 = d.mu0, rho = d.rho;
@@ -80,20 +81,27 @@ __global__ __launch_bounds__(256) void k_epilogue(Grid g, const double* __restri
     __syncthreads();
     if (out.heating_rate && z_profile) {
         const double k = -(1.0 / (1.225 * 1004));            // graphe:71-72: -(1 / (rho c_p))
-        double* hr = out.heating_rate + (size_t)b * L;
+        double* s_hr = s_flux + L;                           // [L]
+        // graphe:83-85: forward difference, the last level copies the one above
         for (int t = tid; t < L; t += blockDim.x) {
-            // graphe:83-91: forward difference, last level copies the one above, then the two levels at the
-            // slab boundaries take the value of their upper neighbour
-            // level whose forward difference ends up at level i after graphe:83-85 (Python indexing: -1 is the last)
-            auto raw = [&](int i) { if (i < 0) i += L; return i == L - 1 ? L - 2 : i; };
-            int s = raw(t);
-            if (d.nz == 3) {
-                const int iu = d.r0[1], id = d.r1[1];
-                if (t == id) s = (id - 1 == iu - 1) ? raw(iu - 2) : raw(id - 1);   // graphe:91 reads what :90 left
-                else if (t == iu - 1) s = raw(iu - 2);                             // graphe:90
-            }
-            hr[t] = k * (s_flux[s + 1] - s_flux[s]) / (z_profile[s + 1] - z_profile[s]);
+            const int s = t == L - 1 ? L - 2 : t;
+            s_hr[t] = k * (s_flux[s + 1] - s_flux[s]) / (z_profile[s + 1] - z_profile[s]);
         }
+        __syncthreads();
+        if (tid == 0 && d.nz >= 3) {
+            // graphe:87-91 'erase_pics', per aerosol zone, in the reference's statement order (Python indexing: -1 is the
+            // last level): the level above a slab and the slab's last level take the value of their upper neighbour
+            for (int z = 1; z < d.nz; ++z) {
+                if (!d.mix[z]) continue;
+                const int iu = d.r0[z], id = d.r1[z];
+                auto at = [&](int i) { return i < 0 ? i + L : i; };
+                s_hr[at(iu - 1)] = s_hr[at(iu - 2)];
+                s_hr[at(id)] = s_hr[at(id - 1)];
+            }
+        }
+        __syncthreads();
+        double* hr = out.heating_rate + (size_t)b * L;
+        for (int t = tid; t < L; t += blockDim.x) hr[t] = s_hr[t];
     }
 }
 
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void k_phase_matrix(Grid g, const double* __re
 
 void launch_epilogue(hipStream_t s, const Grid& g, const double* w, int B, const double* tau, const double* I,
                      const ColDesc* desc, int beam_norm, const double* z_profile, const EpilogueOut& out) {
-    hipLaunchKernelGGL(k_epilogue, dim3(B), dim3(256), (size_t)g.L * sizeof(double), s, g, w, B, tau, I, desc, beam_norm,
+    hipLaunchKernelGGL(k_epilogue, dim3(B), dim3(256), (size_t)2 * g.L * sizeof(double), s, g, w, B, tau, I, desc, beam_norm,
                        z_profile, out);
 }
 

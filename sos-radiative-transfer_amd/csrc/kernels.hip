@@ -92,29 +92,43 @@ __global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, c
         d.wa = sc.alb_atm[b];
         double tref[kMaxZones];
         if (geom == SOSRT_GEOM_THREE_ZONE) {
-            const int iu = sc.idx_up[b], id = sc.idx_down[b];
-            d.nz = 3;
-            d.r0[0] = 0;      d.r1[0] = iu - 1; d.mix[0] = 0;
-            d.r0[1] = iu;     d.r1[1] = id;     d.mix[1] = 1;
-            d.r0[2] = id + 1; d.r1[2] = L - 1;  d.mix[2] = 0;
-            tref[0] = tb[iu - 1]; tref[1] = tb[id]; tref[2] = tb[id];   // spec:342,361,380
+            // The zone table: the reference's three zones (spec:113-449 writes every formula three times) or any
+            // alternation of clear and aerosol zones.  Extrapolation bucket of a zone (I1_In:124, spec:342,361,380): the
+            // optical depth at the zone's own last row for the top zone and for a slab, at the last row of the slab
+            // above for a clear zone below one.
+            const int nz = sc.nz[b];
+            d.nz = nz;
             d.rho = sc.rho[b];
-            d.wr = sc.alb_aer[b];
-            const double da = sc.dtau_atm[b], dr = sc.dtau_aer[b];
-            d.fa = da / (da + dr);
-            d.fr = dr / (da + dr);
             d.tau_bottom = tb[L - 1];
-            d.ca[0] = d.wa / 4; d.cr[0] = 0;
-            d.ca[1] = (d.wa / 4) * d.fa; d.cr[1] = (d.wr / 4) * d.fr;  // spec:321
-            d.ca[2] = d.wa / 4; d.cr[2] = 0;
+            const double da = sc.dtau_atm[b];
+            for (int z = 0; z < kMaxZones; ++z) {
+                if (z < nz) {
+                    d.r0[z] = sc.zr0[b * kMaxZones + z];
+                    d.r1[z] = z + 1 < nz ? sc.zr0[b * kMaxZones + z + 1] - 1 : L - 1;
+                    d.mix[z] = sc.zmix[b * kMaxZones + z];
+                    const double dr = d.mix[z] ? sc.zdtr[b * kMaxZones + z] : 0.0;
+                    d.wr[z] = d.mix[z] ? sc.zwr[b * kMaxZones + z] : 0.0;
+                    d.fa[z] = da / (da + dr);
+                    d.fr[z] = dr / (da + dr);
+                    d.ca[z] = d.mix[z] ? (d.wa / 4) * d.fa[z] : d.wa / 4;            // spec:321,323
+                    d.cr[z] = d.mix[z] ? (d.wr[z] / 4) * d.fr[z] : 0.0;
+                    tref[z] = (z == 0 || d.mix[z]) ? tb[d.r1[z]] : tb[d.r0[z] - 1];
+                } else {
+                    d.r0[z] = L; d.r1[z] = L - 1; d.mix[z] = 0; d.wr[z] = 0; d.fa[z] = 1; d.fr[z] = 0; d.ca[z] = 0; d.cr[z] = 0;
+                    tref[z] = 0;
+                }
+            }
         } else {
             d.nz = 1;
             d.r0[0] = 0; d.r1[0] = L - 1; d.mix[0] = 0;
-            for (int z = 1; z < kMaxZones; ++z) { d.r0[z] = L; d.r1[z] = L - 1; d.mix[z] = 0; d.ca[z] = 0; d.cr[z] = 0; tref[z] = 0; }
+            for (int z = 0; z < kMaxZones; ++z) {
+                if (z) { d.r0[z] = L; d.r1[z] = L - 1; d.mix[z] = 0; d.ca[z] = 0; tref[z] = 0; }
+                d.cr[z] = 0; d.wr[z] = 0; d.fa[z] = 1; d.fr[z] = 0;
+            }
             tref[0] = d.T;                                               // I1_In:124 uses tauStar
-            d.rho = 0; d.wr = 0; d.fa = 1; d.fr = 0;
+            d.rho = 0;
             d.tau_bottom = d.T;                                          // I1_In:54 uses tauStar, not tau[-1]
-            d.ca[0] = d.wa / 4; d.cr[0] = 0;
+            d.ca[0] = d.wa / 4;
         }
         for (int z = 0; z < kMaxZones; ++z) {
             const int k = d_fix_bucket(tref[z]);
@@ -193,13 +207,14 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         const int mm = valid ? m : 0, mir = 2 * N - 1 - mm;
         const double mu = g.mu[mm];
         const double qa = d.wa * P0a[mm] * c4pi, qam = d.wa * P0a[mir] * c4pi;
-        const double qx = (d.wa * P0a[mm] * d.fa + d.wr * P0r[mm] * d.fr) * c4pi;
-        const double qxm = (d.wa * P0a[mir] * d.fa + d.wr * P0r[mir] * d.fr) * c4pi;
+        const double pa = P0a[mm], pam = P0a[mir], pr = P0r[mm], prm = P0r[mir];
         const bool near = fabs(mu + mu0) < 0.0001;          // spec:111
         const bool node = m > N - 2;                         // the mu = 0- node (spec:128-131)
         const double gd = mu0 / (mu0 + mu), gs = mu0 / (mu0 - mu);
         double Ib = 0, vlast = 0;
         for (int z = 0; z < d.nz; ++z) {
+            const double qx = (d.wa * pa * d.fa[z] + d.wr[z] * pr * d.fr[z]) * c4pi;       // spec:149
+            const double qxm = (d.wa * pam * d.fa[z] + d.wr[z] * prm * d.fr[z]) * c4pi;
             const double q = d.mix[z] ? qx : qa, qm = d.mix[z] ? qxm : qam;
             const double t_bd = z ? s_tau[d.r0[z] - 1] : 0.0;
             const double t_bs = z ? s_tau[d.r0[z]] : 0.0;
@@ -244,8 +259,7 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         const int j = valid ? tid : 0, m = N + j, mir = N - 1 - j;
         const double mu = g.mu[m];
         const double qa = d.wa * P0a[m] * c4pi, qam = d.wa * P0a[mir] * c4pi;
-        const double qx = (d.wa * P0a[m] * d.fa + d.wr * P0r[m] * d.fr) * c4pi;
-        const double qxm = (d.wa * P0a[mir] * d.fa + d.wr * P0r[mir] * d.fr) * c4pi;
+        const double pa = P0a[m], pam = P0a[mir], pr = P0r[m], prm = P0r[mir];
         const bool near = fabs(mu - mu0) < 0.0001;           // spec:204
         const bool node = j < 1;                             // the mu = 0+ node (spec:221-224)
         const double gd = mu0 / (mu0 + mu), gs = mu0 / (mu0 - mu);
@@ -253,6 +267,8 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         double vlast = 0;
         for (int z = d.nz - 1; z >= 0; --z) {
             const bool bottom = z == d.nz - 1;
+            const double qx = (d.wa * pa * d.fa[z] + d.wr[z] * pr * d.fr[z]) * c4pi;       // spec:242
+            const double qxm = (d.wa * pam * d.fa[z] + d.wr[z] * prm * d.fr[z]) * c4pi;
             const double q = d.mix[z] ? qx : qa, qm = d.mix[z] ? qxm : qam;
             const double t_bu = bottom ? d.tau_bottom : s_tau[d.r1[z] + 1];
             const double t_bb = bottom ? s_tau[L - 1] : t_bu;
@@ -405,13 +421,12 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     double* s_mup = s_sfc + blockDim.x;      // [blockDim] upward half of the direction grid
     double* s_red = s_mup + blockDim.x;      // [nw + 1]
     __shared__ ColDesc d;                    // dynamically indexed: keep it out of scratch
-    __shared__ FixTab s_fix[kMaxZones];      // the extrapolation table of each zone (read at zone changes)
+    __shared__ FixTab s_fix[4];              // the extrapolation tables, one per tau_ref bucket (a zone names its bucket)
     if (tid == 0) d = a.desc[b];
     s_mup[tid] = tid < N ? g.mu[N + tid] : 1.0;
     {
-        const ColDesc& dg = a.desc[b];
-        for (int zz = 0; zz < kMaxZones; ++zz) {
-            const double* src = reinterpret_cast<const double*>(&g.fix[dg.fixtab[zz]]);
+        for (int zz = 0; zz < 4; ++zz) {
+            const double* src = reinterpret_cast<const double*>(&g.fix[zz]);
             double* dst = reinterpret_cast<double*>(&s_fix[zz]);
             for (int i = tid; i < (int)(sizeof(FixTab) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
         }
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
         bool fixlane = false;
         auto load_fix = [&](int zz) {
             nfx = d.nfix[zz];
-            const FixTab& ft = s_fix[zz];
+            const FixTab& ft = s_fix[d.fixtab[zz]];
             s0 = ft.s0; ns = ft.ns;
             fixlane = valid && nfx > 0 && tid >= N - nfx;
             const int i = fixlane ? N - 1 - tid : 0;

@@ -6,7 +6,8 @@
 
 namespace sosrt {
 
-constexpr int kMaxZones = 3;
+constexpr int kMaxZones = 8;       // zones of a column, top to bottom: clear / slab / clear / slab ... (up to four aerosol slabs)
+constexpr int kRingZones = 3;      // the wave-independent transport kernels (fast, ring) handle the reference's three zones
 
 // One independent SOS problem as the kernels see it: a zone table instead of the reference's
 // three copies of every formula (spec:113-449).
@@ -20,7 +21,10 @@ struct alignas(16) ColDesc {
     int surface;               // SOSRT_SURFACE_*
     int geom;
     double mu0, rho, T, tau_bottom;
-    double wa, wr, fa, fr;     // single-scattering albedos, slab mixing fractions (spec:50-53,149)
+    double wa;                 // single-scattering albedo of the molecules
+    double wr[kMaxZones];      // per zone: single-scattering albedo of its aerosol, slab mixing fractions (spec:50-53,149)
+    double fa[kMaxZones];
+    double fr[kMaxZones];
     double ca[kMaxZones];      // Jn coefficient on In_1 @ W_atm per zone (spec:321,323)
     double cr[kMaxZones];      // Jn coefficient on In_1 @ W_aer per zone
 };
@@ -32,6 +36,14 @@ struct FixTab {
 
 // per-column scalars as uploaded by sosrt_set_columns (structure of arrays)
 struct ColScalars {
+    // zone table of every column ([max_batch][kMaxZones]; filled from idx_up / idx_down by sosrt_set_columns, or given by
+    // the caller through sosrt_set_columns_zones): first row of each zone, 1 for an aerosol slab, the slab's aerosol
+    // single-scattering albedo and optical-depth step
+    const int* nz;
+    const int* zr0;
+    const int* zmix;
+    const double* zwr;
+    const double* zdtr;
     const int* idx_up;
     const int* idx_down;
     const double* mu0;

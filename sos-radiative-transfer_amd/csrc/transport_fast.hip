@@ -48,7 +48,7 @@ __global__ __launch_bounds__(MAXT) void k_transport_fast(TransportArgs a) {
     extern __shared__ double sm[];
     double* s_sfc = sm;                      // [blockDim] surface row by downward lane m (Lambertian only)
     double* s_red = s_sfc + blockDim.x;      // [nw + 1]
-    __shared__ FixTab s_fix[kMaxZones];
+    __shared__ FixTab s_fix[kRingZones];
     __shared__ int s_flag[2];                // [0] redo with the general kernel, [1] IndexError
     const ColDesc* __restrict__ dg = a.desc + b;     // uniform address: scalar loads
     const int nz = dg->nz;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(MAXT) void k_transport_fast(TransportArgs a) {
     const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
     const int surface = dg->surface;
     const double rho = dg->rho;
-    for (int zz = 0; zz < kMaxZones; ++zz) {
+    for (int zz = 0; zz < kRingZones; ++zz) {
         const double* src = reinterpret_cast<const double*>(&g.fix[dg->fixtab[zz]]);
         double* dst = reinterpret_cast<double*>(&s_fix[zz]);
         for (int i = tid; i < (int)(sizeof(FixTab) / sizeof(double)); i += blockDim.x) dst[i] = src[i];

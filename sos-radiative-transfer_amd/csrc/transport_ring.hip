@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
     double* s_x = s_S + (size_t)g.nsmall * L;                  // [TC][64] rows of the wave that holds a mu -> 0 neighbourhood
     double* s_prmu = s_x + TC * 64;                            // [16] 1/mu of the first upward directions
-    __shared__ FixTab s_fix[kMaxZones];
+    __shared__ FixTab s_fix[kRingZones];
     __shared__ int s_flag[2];                                  // [0] redo with the general kernel, [1] IndexError
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     if (loader) {
         for (int q = 0; q < min(R, NQ); ++q) issue(q);
     } else {
-        for (int zz = 0; zz < kMaxZones; ++zz) {
+        for (int zz = 0; zz < kRingZones; ++zz) {
             const double* src = reinterpret_cast<const double*>(&g.fix[dg->fixtab[zz]]);
             double* dst = reinterpret_cast<double*>(&s_fix[zz]);
             for (int i = tid; i < (int)(sizeof(FixTab) / sizeof(double)); i += ncomp) dst[i] = src[i];

@@ -34,6 +34,7 @@ SIGNATURES = {
     "sosrt_set_grid": (c_int, [c_void_p, c_void_p]),
     "sosrt_set_phase": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sosrt_set_columns": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 9),
+    "sosrt_set_columns_zones": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 10),
     "sosrt_first_order": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sosrt_source": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "sosrt_transport": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -63,6 +63,31 @@ def tau_profile(tauStar_atm, tauStar_aer, z0, z_up, z_down, nb_layers):
     return tau
 
 
+def tau_profile_slabs(tauStar_atm, slabs, z0, nb_layers):
+    """SOS_Aer_tau_profile.py:15-27 with several aerosol layers: `slabs` = [(z_up, z_down, tauStar_aer), ...]
+    from the top down, each a linear ramp of its aerosol optical depth over its rows on top of the uniform molecular
+    profile.  Returns (tau [L], zone_r0, zone_mix, zone_dtau_aer) -- the zone table `Solver.set_columns_zones` takes:
+    clear and aerosol zones alternating.  One slab gives `tau_profile` and the reference's three zones."""
+    L = int(nb_layers)
+    z = np.linspace(z0, 0, L)
+    tau = np.arange(0, L) * tauStar_atm / (L - 1)
+    r0, mix, dta, prev = [0], [0], [0.0], 0
+    for z_up, z_down, t_aer in slabs:
+        if z_down > z_up:
+            z_down, z_up = z_up, z_down
+        iu, idn = int(np.argmin(np.abs(z - z_up))), int(np.argmin(np.abs(z - z_down)))
+        if not (iu > prev and idn >= iu and idn <= L - 2):
+            raise ValueError("aerosol layers must be given from the top down, separated by clear rows and above the last row")
+        step = t_aer / (idn + 1 - iu)
+        k = np.arange(L)
+        tau = tau + np.where(k < iu, 0.0, np.where(k <= idn, (k + 1 - iu) * step, t_aer))
+        r0 += [iu, idn + 1]
+        mix += [1, 0]
+        dta += [step, 0.0]
+        prev = idn + 1
+    return tau, np.array(r0, dtype=np.int32), np.array(mix, dtype=np.int32), np.array(dta)
+
+
 def _ring_average(p, mu_a, mu_b, nb_phi=25):
     phi = np.linspace(0, np.pi, nb_phi)
     cc = mu_a[:, None] * mu_b[None, :]

@@ -122,6 +122,27 @@ class Solver:
         check(lib().sosrt_set_columns(self._h, B, _lib.GEOM_THREE_ZONE, sf, _ptr(iu), _ptr(idn), *[_ptr(x) for x in v]))
         self.B = B
 
+    def set_columns_zones(self, zone_r0, zone_mix, mu0, grd_alb, alb_atm, dtau_atm, zone_alb_aer, zone_dtau_aer, tauStar_tot,
+                          nz=None, surface="specular"):
+        """Columns described by a zone table: `zone_r0`, `zone_mix` [B, nzmax] (first row of each zone, 1 for an
+        aerosol zone), `zone_alb_aer`, `zone_dtau_aer` [B, nzmax] (per aerosol zone), `nz` [B] zones per column (default:
+        all nzmax).  (clear, slab, clear) is `set_columns`."""
+        zr0 = np.ascontiguousarray(np.atleast_2d(zone_r0), dtype=np.int32)
+        B, nzmax = zr0.shape
+        zmix = np.ascontiguousarray(np.broadcast_to(np.asarray(zone_mix, dtype=np.int32), (B, nzmax)))
+        zwr = np.ascontiguousarray(np.broadcast_to(np.asarray(zone_alb_aer, dtype=np.float64), (B, nzmax)))
+        zdt = np.ascontiguousarray(np.broadcast_to(np.asarray(zone_dtau_aer, dtype=np.float64), (B, nzmax)))
+        nzv = np.full(B, nzmax, dtype=np.int32) if nz is None else _i32(np.reshape(nz, (B,)), B, "nz")
+        sf = {"specular": _lib.SURFACE_SPECULAR, "lambertian": _lib.SURFACE_LAMBERTIAN,
+              "lambertian_readme": _lib.SURFACE_LAMBERTIAN_README}.get(surface)
+        if sf is None:
+            raise ValueError("surface must be 'specular', 'lambertian' or 'lambertian_readme', got %r" % (surface,))
+        v = [_vec(x, B, n) for x, n in ((mu0, "mu0"), (grd_alb, "grd_alb"), (alb_atm, "alb_atm"), (dtau_atm, "dtau_atm"),
+                                        (tauStar_tot, "tauStar_tot"))]
+        check(lib().sosrt_set_columns_zones(self._h, B, sf, nzmax, _ptr(nzv), _ptr(zr0), _ptr(zmix), _ptr(v[0]), _ptr(v[1]),
+                                            _ptr(v[2]), _ptr(v[3]), _ptr(zwr), _ptr(zdt), _ptr(v[4])))
+        self.B = B
+
     def set_columns_single_slab(self, mu0, alb, tauStar):
         """Single homogeneous slab over a black surface (I1_In:13-130)."""
         B = int(np.size(mu0))

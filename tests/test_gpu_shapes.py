@@ -338,3 +338,60 @@ def test_float_contraction_is_an_opt_in_that_misses_the_parity_bar():
     e = np.max(np.abs(j32 - j64)) / np.max(np.abs(j64))
     assert 1e-9 < e < 1e-5
     s.close()
+
+
+def test_zone_table_columns():
+    """columns described by a zone table.  (clear, slab, clear) through sosrt_set_columns_zones equals
+    sosrt_set_columns bit for bit; columns with two aerosol layers (five zones, general transport kernel, dense tiling of
+    the contraction) match the oracle's zone-table path, fluxes and heating rate included (the 'erase_pics' fix-up at
+    both layers).  More than one slab is parity unpinned by construction (the reference has one)."""
+    L, N, B = 48, 64, 5
+    mu = inputs.direction_grid(N)
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, 0.6)
+    P0r, Pr = inputs.phase_function("hg", N, mu, 0.6, 0.7)
+    # (a) the reference's three zones, both entry points
+    tau, r0, mix, dta = inputs.tau_profile_slabs(0.124, [(25, 17, 0.3)], 120, L)
+    iu, idn = inputs.slab_indices(120, 25, 17, L)
+    assert np.array_equal(tau, inputs.tau_profile(0.124, 0.3, 120, 25, 17, L)) and list(r0) == [0, iu, idn + 1]
+    s = Solver(L, N, max_batch=B, max_orders=100)
+    s.set_grid(mu); s.set_phase(Pa, Pr)
+    rho = np.linspace(0.0, 0.6, B)
+    s.set_columns(np.full(B, iu), np.full(B, idn), 0.6, rho, 1.0, 0.95, 0.124 / L, dta[1], 0.424)
+    a = s.solve(np.tile(tau, (B, 1)), np.tile(P0a, (B, 1)), np.tile(P0r, (B, 1)))
+    s.set_columns_zones(np.tile(r0, (B, 1)), mix, 0.6, rho, 1.0, 0.124 / L, 0.95, dta, 0.424)
+    b = s.solve(np.tile(tau, (B, 1)), np.tile(P0a, (B, 1)), np.tile(P0r, (B, 1)))
+    assert np.array_equal(a.n, b.n) and np.array_equal(a.I, b.I)
+    # (b) two aerosol layers with different albedos and optical depths, different per column
+    slabs = [[(60, 50, 0.2, 0.90), (25, 17, 0.4, 0.97)], [(70, 55, 0.05, 1.0), (30, 10, 1.2, 0.85)], [(60, 50, 0.6, 0.95), (25, 17, 0.1, 0.8)]]
+    cols = [O.make_column_slabs(0.6, 120, sl, L, 0.124, 0.1 + 0.2 * i, 1.0, N, P0a, Pa, P0r, Pr) for i, sl in enumerate(slabs)]
+    Bz = len(cols)
+    zr0 = np.array([[z.r0 for z in c.zones] for c in cols], dtype=np.int32)
+    zmix = np.array([[z.kind == "mix" for z in c.zones] for c in cols], dtype=np.int32)
+    zwr = np.array([[z.alb_aer for z in c.zones] for c in cols])
+    zdt = np.array([[z.dtau_aer for z in c.zones] for c in cols])
+    for c, sl in zip(cols, slabs):      # the product's grid builder gives the oracle's grid and table
+        t2, r2, m2, d2 = inputs.tau_profile_slabs(0.124, [x[:3] for x in sl], 120, L)
+        assert np.array_equal(t2, c.tau) and list(r2) == [z.r0 for z in c.zones] and np.array_equal(d2, [z.dtau_aer for z in c.zones])
+    s.set_columns_zones(zr0, zmix, 0.6, [c.grd_alb for c in cols], 1.0, 0.124 / L, zwr, zdt, [c.tauStar_tot for c in cols])
+    tau3 = np.stack([c.tau for c in cols])
+    r = s.solve(tau3, np.tile(P0a, (Bz, 1)), np.tile(P0r, (Bz, 1)), fetch_field=True)
+    z = np.linspace(120, 0, L)
+    e = s.epilogue(z_profile=z)
+    for i, c in enumerate(cols):
+        ref = O.solve_column(c, literal=False)
+        assert int(r.n[i]) == ref.n and int(r.status[i]) == 0
+        assert_close(r.I[i], ref.I, RTOL, "two-slab column %d" % i)
+        fd, fu = O.fluxes(ref.I, mu, c.tau, N, 0.6, c.grd_alb)
+        assert_close(e["flux_down"][i], fd, RTOL, "flux down")
+        pairs = [(zn.r0, zn.r1) for zn in c.zones if zn.kind == "mix"]
+        hr = O.heating_rate(ref.I, mu, c.tau, N, 0.6, c.grd_alb, z, 0, 0, slabs=pairs)
+        scale = np.max(np.abs(fd + fu)) / (1.225 * 1004 * abs(z[1] - z[0]))
+        assert np.max(np.abs(e["heating_rate"][i] - hr)) <= RTOL * scale
+        for iu2, id2 in pairs:
+            assert e["heating_rate"][i][iu2 - 1] == e["heating_rate"][i][iu2 - 2] and e["heating_rate"][i][id2] == e["heating_rate"][i][id2 - 1]
+    # argument checks
+    with pytest.raises(ValueError):
+        s.set_columns_zones([[0, 10, 20]], [[1, 0, 0]], 0.6, 0.1, 1.0, 0.124 / L, 0.9, 0.01, 0.3)      # aerosol zone at the top
+    with pytest.raises(ValueError):
+        s.set_columns_zones([[0, 20, 10]], [[0, 1, 0]], 0.6, 0.1, 1.0, 0.124 / L, 0.9, 0.01, 0.3)      # not ascending
+    s.close()

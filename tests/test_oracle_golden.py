@@ -60,6 +60,31 @@ def test_columns(path):
             assert_close(s.I_saved[k], d["I_saved"][k], PIN * 50, "order %d" % (k + 1))
 
 
+def test_zone_table_reduces_to_the_three_zones():
+    """The zone-table generalisation (SURVEY 8f-4) with the reference's three zones is the same arithmetic, bit for bit;
+    two aerosol layers run, stay positive and converge (more than one slab is parity unpinned: the reference has one)."""
+    d, c = column_case(golden("g3_spec_L60_N64_ray_hg_mu0node.npz")[0])
+    col = oracle_column(O, c)
+    a = O.solve_column(col, literal=False)
+    L = c["L"]
+    tab = [O._Zone(0, c["idx_up"] - 1, "atm"), O._Zone(c["idx_up"], c["idx_down"], "mix", c["alb_aer"], c["dtau_aer"]),
+           O._Zone(c["idx_down"] + 1, L - 1, "atm")]
+    import dataclasses
+    b = O.solve_column(dataclasses.replace(col, zone_table=tab), literal=False)
+    assert a.n == b.n and np.array_equal(a.I, b.I)
+    tau1, rows = O.tau_profile_slabs(c["tauStar_atm"], [(c["z_up"], c["z_down"], c["tauStar_aer"])], c["z0"], L)
+    assert np.array_equal(tau1, col.tau) and rows == [(c["idx_up"], c["idx_down"])]
+    two = O.make_column_slabs(0.6, 120, [(60, 50, 0.2, 0.9), (25, 17, 0.4, 0.97)], 48, 0.124, 0.3, 1.0, 64,
+                              c["P0_atm"], c["P_atm"], c["P0_aer"], c["P_aer"])
+    assert len(two.zones) == 5 and [z.kind for z in two.zones] == ["atm", "mix", "atm", "mix", "atm"]
+    s2 = O.solve_column(two, literal=False)
+    assert 5 < s2.n < 60 and np.all(s2.I[:, 1:64 - 1] >= 0) and np.isfinite(s2.I).all()
+    # literal and vectorised transport agree on the table too
+    s3 = O.solve_column(two, literal=True)
+    assert s3.n == s2.n
+    assert_close(s3.I, s2.I, PIN * 50, "two slabs, literal vs vectorised")
+
+
 def test_c2_digest():
     """C2 shape (L=200, N=128, Rayleigh + HG 0.7): digests only, vectorised oracle."""
     d, c = column_case(golden("g4_spec_C2_*.npz")[0])
