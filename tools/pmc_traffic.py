@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch and kernel family from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over tools/run_once.py.
+
+usage: python3 tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <solves> > profiles/rNN_pmc_traffic.json
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streams; counter unit KB = 1024 B."""
+import csv, hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def family(name):
+    for k in ("k_jn_gemm", "k_transport_ring", "k_transport_fast", "k_transport", "k_first_order", "k_attenuation", "k_smallmu", "k_epilogue",
+              "k_phase_p0", "k_prepare", "k_tau_hash", "k_tau_rep", "k_wmix", "k_finalize"):
+        if k in name:
+            return k
+    return None
+
+
+def collect(path, counter):
+    tot, cnt = {}, {}
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        f = family(r["Kernel_Name"])
+        if f is None:
+            continue
+        tot[f] = tot.get(f, 0.0) + float(r["Counter_Value"])
+        cnt[f] = cnt.get(f, 0) + 1
+    return tot, cnt
+
+
+def sha():
+    h = hashlib.sha256()
+    for name in ("jn_gemm.hip", "transport_ring.hip", "kernels.hpp", "transport_util.hpp"):
+        h.update(open(os.path.join(ROOT, "sos-radiative-transfer_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+fetch, fc = collect(sys.argv[1], "FETCH_SIZE")
+write, wc = collect(sys.argv[2], "WRITE_SIZE")
+solves = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+out = {}
+for f in sorted(set(fetch) | set(write)):
+    n = max(fc.get(f, 0), wc.get(f, 0))
+    fb = 2.0 * 1024 * fetch.get(f, 0.0) / max(n, 1)
+    wb = 1024 * write.get(f, 0.0) / max(n, 1)
+    out[f] = {"launches_per_solve": n / solves, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+out["kernel_sources_sha"] = sha()
+out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/run_once.py 512 %d "
+                "(solves of the bench sweep); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streams; counter "
+                "unit KB = 1024 B; averages over all launches, k_jn_gemm = the three tilings of the contraction; bench.py uses this file "
+                "only while kernel_sources_sha matches the kernel sources" % solves)
+print(json.dumps(out, indent=1))
