@@ -131,6 +131,47 @@ def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, 
     return BatchResult(I=r.I, n=r.n, status=r.status, tau=tau, mu=mu, idx_up=iu, idx_down=idn, I_saved=r.I_saved)
 
 
+def SOS_Aer_layers(mu0, grd_alb, slabs, *, tauStar_atm=0.124, alb_atm=1.0, z0=120, nb_layers=200, nb_angles=128,
+                   atm_phase_fun="rayleigh", g_atm=0.0, aer_phase_fun="hg", g_aer=0.7, P_atm=None, P_aer=None, surface="specular",
+                   tol=1e-4, max_orders=256, device=0, raise_on_error=True) -> BatchResult:
+    """Columns with SEVERAL aerosol layers (the reference has one): `slabs` = [(z_up, z_down, tauStar_aer,
+    alb_aer), ...] from the top down, shared by the B columns of the arrays `mu0`, `grd_alb`.  Every formula of the path is
+    evaluated per zone as the reference writes it for its three zones; one layer gives `SOS_Aer_batch`'s result bit for
+    bit.  All layers share the aerosol phase function.  `idx_up` / `idx_down` of the result are those of the first layer."""
+    from .inputs import tau_profile_slabs
+    mu0, grd_alb = np.broadcast_arrays(np.atleast_1d(np.asarray(mu0, dtype=np.float64)), np.atleast_1d(np.asarray(grd_alb, dtype=np.float64)))
+    B, L, N = mu0.shape[0], int(nb_layers), int(nb_angles)
+    mu = direction_grid(N)
+    tau, r0, mix, dta = tau_profile_slabs(tauStar_atm, [s[:3] for s in slabs], z0, L)
+    zwr = np.zeros(len(r0))
+    zwr[1::2] = [s[3] for s in slabs]
+    if P_atm is None:
+        P_atm = phase_function(atm_phase_fun, N, mu, 0.5, g_atm)[1]
+    if P_aer is None:
+        P_aer = phase_function(aer_phase_fun, N, mu, 0.5, g_aer)[1]
+    s = get_solver(L, N, B, max_orders, device)
+    if not s.same_grid(mu):
+        s.set_grid(mu)
+    if not s.same_phase(P_atm, P_aer):
+        s.set_phase(P_atm, P_aer)
+    # P0(mu, mu0) per column on the device for the analytic phase functions, on the host otherwise
+    def p0(name, g):
+        if name in ("iso", "rayleigh", "hg", "fwc"):
+            if name == "fwc":
+                from .inputs import fwc_table
+                s.set_phase_table(*fwc_table())
+            return s.phase_p0({"fwc": "table"}.get(name, name), mu0, g)
+        cache = {float(m): phase_function(name, N, mu, float(m), g)[0] for m in np.unique(mu0)}
+        return np.stack([cache[float(m)] for m in mu0])
+    P0a, P0r = p0(atm_phase_fun, g_atm), p0(aer_phase_fun, g_aer)
+    s.set_columns_zones(np.tile(r0, (B, 1)), mix, mu0, grd_alb, alb_atm, tauStar_atm / L, zwr, dta,
+                        tauStar_atm + sum(x[2] for x in slabs), surface=surface)
+    r = s.solve(np.tile(tau, (B, 1)), P0a, P0r, tol=tol)
+    if raise_on_error:
+        _raise_status(r.status, N)
+    return BatchResult(I=r.I, n=r.n, status=r.status, tau=np.tile(tau, (B, 1)), mu=mu, idx_up=int(r0[1]), idx_down=int(r0[2]) - 1)
+
+
 def SOS_Aer(surface="specular", tol=1e-4, max_orders=256, P_atm=None, P0_atm=None, P_aer=None, P0_aer=None, device=0,
             **overrides) -> ColumnResult:
     """One column with the reference's parameter names (spec:19-96).  `surface` selects the file of

@@ -389,6 +389,18 @@ def test_zone_table_columns():
         assert np.max(np.abs(e["heating_rate"][i] - hr)) <= RTOL * scale
         for iu2, id2 in pairs:
             assert e["heating_rate"][i][iu2 - 1] == e["heating_rate"][i][iu2 - 2] and e["heating_rate"][i][id2] == e["heating_rate"][i][id2 - 1]
+    # the column-level entry point: one layer = SOS_Aer_batch bit for bit (P0 built on the device for both here), two layers = oracle
+    from sosrt.main import SOS_Aer_layers
+    m0 = np.array([0.35, 0.6, 0.9])
+    one = SOS_Aer_layers(m0, 0.2, [(25, 17, 0.3, 0.95)], nb_layers=L, nb_angles=N, max_orders=100)
+    P0a3 = s.phase_p0("rayleigh", m0); P0r3 = s.phase_p0("hg", m0, 0.7)
+    ref1 = SOS_Aer_batch(m0, 0.3, 0.2, alb_aer=0.95, nb_layers=L, nb_angles=N, max_orders=100, P0_atm=P0a3, P0_aer=P0r3)
+    assert np.array_equal(one.I, ref1.I) and np.array_equal(one.n, ref1.n)
+    two = SOS_Aer_layers([0.6], [0.1], slabs[0], nb_layers=L, nb_angles=N, max_orders=100)
+    assert_close(two.I[0], O.solve_column(cols[0], literal=False).I, RTOL, "SOS_Aer_layers, two layers")
+    s.close()
+    s = Solver(L, N, max_batch=B, max_orders=100)
+    s.set_grid(mu); s.set_phase(Pa, Pr)
     # argument checks
     with pytest.raises(ValueError):
         s.set_columns_zones([[0, 10, 20]], [[1, 0, 0]], 0.6, 0.1, 1.0, 0.124 / L, 0.9, 0.01, 0.3)      # aerosol zone at the top
