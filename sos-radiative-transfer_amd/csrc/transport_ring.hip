@@ -46,7 +46,7 @@ __device__ __forceinline__ void wg_barrier() {
 }
 
 template <bool ACC, bool SAVED, int PIECES>
-__global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int NWL, int dbg_arg) {
+__global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int NWL, int dbg_arg, int fixcap) {
 #ifdef SOSRT_RING_DEBUG
     const int dbg = dbg_arg;            // diagnostic builds only (-DSOSRT_RING_DEBUG): timing switches that corrupt the results
 #else
@@ -79,13 +79,15 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     constexpr int IPC = NARR * TC * PIECES;                    // wave-instructions per chunk
     extern __shared__ double sm[];
     double* ring = sm;                                         // [NS][NARR][TC][RS]
-    double* s_sfc = ring + (size_t)NS * SLOT;                  // [blockDim] surface row by downward lane m
-    double* s_red = s_sfc + blockDim.x;                        // [nw + 1]
+    double* s_sfc = ring + (size_t)NS * SLOT;                  // [RS] surface row by downward lane m
+    double* s_red = s_sfc + RS;                                // [nw + 1]
     double* s_hd = s_red + (blockDim.x >> 6) + 2;              // [L + 1] half layer thicknesses: hd[t] = (tau[t] - tau[t-1]) / 2
     double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
     double* s_x = s_S + (size_t)g.nsmall * L;                  // [TC][64] rows of the wave that holds a mu -> 0 neighbourhood
     double* s_prmu = s_x + TC * 64;                            // [16] 1/mu of the first upward directions
-    __shared__ FixTab s_fix[kRingZones];
+    double* s_fixc = s_prmu + 16;                              // [kRingZones][fixcap][kFixMaxSrc]
+    // the extrapolation coefficients of each zone, compact ([zone][fixcap rewritten directions][5 sources]): with the ring
+    // and the row buffers a workgroup then needs less than half the LDS of a CU, so two columns share one
     __shared__ int s_flag[2];                                  // [0] redo with the general kernel, [1] IndexError
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
@@ -174,9 +176,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         for (int q = 0; q < min(R, NQ); ++q) issue(q);
     } else {
         for (int zz = 0; zz < kRingZones; ++zz) {
-            const double* src = reinterpret_cast<const double*>(&g.fix[dg->fixtab[zz]]);
-            double* dst = reinterpret_cast<double*>(&s_fix[zz]);
-            for (int i = tid; i < (int)(sizeof(FixTab) / sizeof(double)); i += ncomp) dst[i] = src[i];
+            const FixTab& src = g.fix[dg->fixtab[zz]];
+            for (int i = tid; i < fixcap * kFixMaxSrc; i += ncomp) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
         }
         if (tid < 2) s_flag[tid] = 0;
         const double* __restrict__ tau = a.tau + (size_t)b * L;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         int nfx = 0;
         bool fixlane = false;
         auto load_fix = [&](int zz) {
-            const FixTab& ft = s_fix[zz];
+            const double* ftC = s_fixc + zz * fixcap * kFixMaxSrc;
             nfx = zz == 0 ? nfix0 : (zz == 1 ? nfix1 : nfix2);
             const int ns = nfx < 2 ? 2 : (nfx < kFixMaxSrc ? nfx : kFixMaxSrc);     // In_limit:118-141
             fixlane = valid && nfx > 0 && m >= N - nfx;
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             const int s0 = nfx < 2 ? N - nfx - 2 : N - nfx - ns;
 #pragma unroll
             for (int q = 0; q < kFixMaxSrc; ++q) {
-                c[q] = (fixlane && q < ns) ? ft.C[i * ns + min(q, ns - 1)] : 0.0;
-                cT[q] = (pT < nfx && q < ns) ? ft.C[pT * ns + min(q, ns - 1)] : 0.0;
+                c[q] = (fixlane && q < ns) ? ftC[i * ns + min(q, ns - 1)] : 0.0;
+                cT[q] = (pT < nfx && q < ns) ? ftC[pT * ns + min(q, ns - 1)] : 0.0;
                 sl[q] = (s0 + min(q, ns - 1)) & 63;
             }
         };
@@ -539,8 +540,11 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 }
 
 // doubles of LDS besides the ring: surface row, reduction slots, half thicknesses, small-mu rows
+// rewritten directions the compact coefficient tables hold: the largest int(c N) of In_limit / I1_In:124-127
+inline int ring_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
 inline size_t ring_extra_doubles(const Grid& g, int nt) {
-    return (size_t)nt + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 64 + 16;
+    const int rs = g.N <= 128 ? 128 : 256;
+    return (size_t)rs + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 64 + 16 + (size_t)kRingZones * ring_fixcap(g) * kFixMaxSrc;
 }
 
 template <int PIECES>
@@ -557,7 +561,7 @@ void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int 
                                 (int)kRingLdsBytes);                                                                   \
             big_lds = true;                                                                                    \
         }                                                                                                      \
-        hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, NWL, g_ring_debug);                                             \
+        hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, NWL, g_ring_debug, ring_fixcap(a.g));                           \
     } while (0)
     if (a.accumulate) {
         if (a.saved) SOSRT_RING_LAUNCH(true, true);
