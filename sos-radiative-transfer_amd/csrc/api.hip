@@ -812,7 +812,7 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
         HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E,
                          (h->transport_mode == 2 && h->ring_ok) ? 3 : 1);
-        if (h->N - 3 > 61)
+        if (h->N - 3 > 61 && !(h->transport_mode == 2 && h->ring_ok))
             launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 2);
     } else {
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, nullptr, 0);
@@ -976,9 +976,9 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0);
-                if (h->N - 3 > 61)     // a search that leaves wave 0 is redone by the general kernel (flag cv.redo)
+                if (h->N - 3 > 61 && fast_mode == 1)     // register-streaming kernel: a search that leaves wave 0 is redone by the
                     launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
-                                     h->d_E, 2, erep_g);
+                                     h->d_E, 2, erep_g);         // general kernel (flag cv.redo); the ring kernel redoes it itself
             } else {
                 launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->use_etab ? h->d_E : nullptr, 0, erep_g);

@@ -24,6 +24,11 @@ __device__ __forceinline__ double bload(__amdgpu_buffer_rsrc_t r, int voff, int 
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return __hiloint2double((int)v.y, (int)v.x);
 }
+// the same past the L1 (glc): for data this workgroup stored earlier in the kernel
+__device__ __forceinline__ double bload_glc(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 1);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x) {
     u32x2 v;
     v.x = (unsigned)__double2loint(x);
