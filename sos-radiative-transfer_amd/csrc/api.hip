@@ -415,8 +415,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_mixcr, sosrt_handle::kMaxMixGroups))) return e;
             if ((e = dalloc(&h->d_tauhash, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
-            HIPCHK(hipHostMalloc((void**)&h->h_pub, 8 * sosrt_handle::kMaxGroups * sizeof(int), hipHostMallocCoherent));
-            memset(h->h_pub, 0, 8 * sosrt_handle::kMaxGroups * sizeof(int));
+            // + 2 ints at the end: {needs k_smallmu, tag} published at the start of a solve
+            HIPCHK(hipHostMalloc((void**)&h->h_pub, (8 * sosrt_handle::kMaxGroups + 2) * sizeof(int), hipHostMallocCoherent));
+            memset(h->h_pub, 0, (8 * sosrt_handle::kMaxGroups + 2) * sizeof(int));
 
             HIPCHK(hipMemset(h->d_Wa, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
             HIPCHK(hipMemset(h->d_Wr, 0, (size_t)g.Dp * g.Wld * sizeof(double)));
@@ -877,12 +878,16 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr,
                    h->d_nactive + sosrt_handle::kMaxGroups);
     h->need_small = true;
+    const int small_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;       // never equals an order tag
+    bool small_published = false;
     const bool fast = h->transport_mode >= 1 && h->fast_ok && h->max_nz <= kRingZones;   // more zones: the general kernel
     const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) {
         // one attenuation table per distinct optical-depth profile
-        launch_tau_groups(s, g, B, d_tau, h->d_tauhash, h->d_erep);
+        launch_tau_groups(s, g, B, d_tau, h->d_tauhash, h->d_erep, h->d_nactive + sosrt_handle::kMaxGroups,
+                          h->h_pub + 8 * sosrt_handle::kMaxGroups, small_tag);
         launch_attenuation(s, g, B, d_tau, h->d_E, h->d_erep);
+        small_published = true;
     }
     if (fast) HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), s));
     if (h->mix_groups > 0 && h->mix_dirty) {
@@ -932,6 +937,17 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         prof_end(h, SOSRT_K_FIRST, k);
     };
     start_group(0);
+    if (small_published && g.nsmall > 0) {
+        // k_prepare's verdict on k_smallmu, published by the second kernel of the solve: by now it has long run
+        volatile int* slot = h->h_pub + 8 * sosrt_handle::kMaxGroups;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 1; __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != small_tag; ++it) {
+            if ((it & 0x3fff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return fail(SOSRT_E_HIP, "order loop: no progress for 120 s");
+            __builtin_ia32_pause();
+        }
+        h->need_small = slot[0] != 0;
+    }
     int live_groups = NG, n_max = 1;
     while (live_groups > 0) {
         for (int k = 0; k < NG; ++k) {

@@ -780,8 +780,16 @@ void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, 
 // per profile keeps the tables in L2 / MALL instead of streaming one per column from HBM in every
 // order.  k_tau_hash: one 64-bit hash per column; k_tau_rep: the first earlier column with the same
 // hash and, checked value by value, the same profile.
-__global__ void k_tau_hash(int L, const double* __restrict__ tau_all, unsigned long long* __restrict__ hash) {
+__global__ void k_tau_hash(int L, const double* __restrict__ tau_all, unsigned long long* __restrict__ hash,
+                           const int* __restrict__ need_small, int* __restrict__ host_flag, int tag) {
     const int b = blockIdx.x, lane = threadIdx.x;            // one wave per column
+    // k_prepare (the previous kernel of the stream) has decided whether any |mu| < 0.01 lane keeps its k_smallmu value: tell
+    // the host now, so that the order loop can drop those launches -- and the ring kernel their LDS rows, which lets two
+    // columns share a CU -- from the second order on instead of the fifth
+    if (host_flag && b == 0 && lane == 0) {
+        __hip_atomic_store(host_flag, need_small[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_flag + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const unsigned long long* t = reinterpret_cast<const unsigned long long*>(tau_all + (size_t)b * L);
     unsigned long long h = 0;
     for (int i = lane; i < L; i += 64) {
@@ -813,8 +821,9 @@ __global__ void k_tau_rep(int L, const double* __restrict__ tau_all, const unsig
     }
     if (lane == 0) erep[b] = rep;
 }
-void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep) {
-    hipLaunchKernelGGL(k_tau_hash, dim3(B), dim3(64), 0, s, g.L, tau, hash);
+void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep,
+                       const int* need_small, int* host_flag, int tag) {
+    hipLaunchKernelGGL(k_tau_hash, dim3(B), dim3(64), 0, s, g.L, tau, hash, need_small, host_flag, tag);
     hipLaunchKernelGGL(k_tau_rep, dim3(B), dim3(64), 0, s, g.L, tau, hash, erep);
 }
 

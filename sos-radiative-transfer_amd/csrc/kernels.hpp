@@ -194,7 +194,9 @@ bool transport_fast_ok(const Plan& plan);
 // erep (nullable): tables are built only for columns with erep[b] == b
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep);
 // erep[b] = first column with the same optical-depth profile as column b (hash[B] is scratch)
-void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep);
+// need_small / host_flag / tag (nullable): publishes k_prepare's verdict on k_smallmu to pinned host memory {flag, tag}
+void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep,
+                       const int* need_small = nullptr, int* host_flag = nullptr, int tag = 0);
 void launch_fluxes(hipStream_t s, const Grid& g, int B, const double* tau, const double* I, const ColDesc* desc,
                    int beam_norm, double* fdn, double* fup);
 // epilogue.hip: outputs of the epilogue (each nullable): [B][L] per level, net_toa [B]
