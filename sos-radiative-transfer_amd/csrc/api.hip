@@ -66,6 +66,8 @@ struct sosrt_handle {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ngroups = 1, want_groups = 1, split_min = 256;
+    int coresident_pad = 27008;         // SOSRT_GEMM_PAD_LDS: 27 656 static + this > 1/3 of 160 KiB
+    int coresident_slots = 2;           // SOSRT_GROUP_RING_SLOTS: ring depth of the transport when two groups share the CUs
     double stagger = 1.0;                // a group starts when the previous one is down to this fraction of live columns (SOSRT_STAGGER; 1: together)
     int gb[kMaxGroups + 1] = {0, 0, 0};                    // column range of group g: [gb[g], gb[g+1])
     int main_off[kMaxGroups + 1] = {0, 0, 0};              // its plain rows in d_mainrows
@@ -283,6 +285,10 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
     }
     ga.rows_slab = h->d_slabrows + h->slab_off[g0]; ga.n_slab = h->slab_off[g1] - h->slab_off[g0];
     ga.D = h->g.D; ga.Dp = h->g.Dp; ga.Wld = h->g.Wld; ga.L = h->L; ga.C = Jn; ga.active = active;
+    // Two column groups: the large tilings of the contraction are capped at two workgroups per CU (unused LDS up to a
+    // third of the CU's) so that a transport workgroup of the other group -- 53 KB with a two-slot ring -- runs beside
+    // them: the MFMA-bound contraction of one group then overlaps the HBM-bound transport of the other
+    if (grp >= 0 && h->ngroups > 1) ga.pad_lds = h->coresident_pad;
     if (pub_tag) {
         ga.nactive = h->d_nactive + pg; ga.need_small = h->d_nactive + sosrt_handle::kMaxGroups;
         ga.host_pub = h->h_pub + 8 * pg; ga.tag = pub_tag;
@@ -352,6 +358,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
     if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
     if (const char* ev = getenv("SOSRT_STAGGER")) h->stagger = atof(ev);
+    if (const char* ev = getenv("SOSRT_GEMM_PAD_LDS")) h->coresident_pad = atoi(ev);
+    if (const char* ev = getenv("SOSRT_GROUP_RING_SLOTS")) h->coresident_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_LOADERS")) g_ring_loaders = atoi(ev);
 #ifdef SOSRT_RING_DEBUG   // diagnostic builds only: the switches make the ring kernel skip work, its results are wrong
@@ -991,7 +999,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 Grid gt = g;
                 if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
-                                 h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0);
+                                 h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0);
                 if (h->N - 3 > 61 && fast_mode == 1)     // register-streaming kernel: a search that leaves wave 0 is redone by the
                     launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                      h->d_E, 2, erep_g);         // general kernel (flag cv.redo); the ring kernel redoes it itself

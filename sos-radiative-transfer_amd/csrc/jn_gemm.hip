@@ -333,7 +333,7 @@ void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_til
     const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
     dim3 grid((unsigned)((cols * (ts + tm) + 7) / 8 * 8 * nct));
     if (small_tiles) hipLaunchKernelGGL(k_jn_gemm_tail, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_jn_gemm_cols, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_jn_gemm_cols, grid, dim3(256), (size_t)a.pad_lds, s, a);
 }
 
 // Wmix[g] = ca[g] W_atm + cr[g] W_aer for every distinct slab coefficient pair of the batch
@@ -354,7 +354,7 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     if (tiles <= 0) return;
     const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
     dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nct));
-    hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), (size_t)a.pad_lds, s, a);
 }
 
 }  // namespace sosrt

@@ -117,6 +117,7 @@ struct TransportArgs {
     // sweep tend to share their index modulo 8).
     int live = 0;
     const int* live_list = nullptr;
+    int slots = 0;             // ring depth of this launch (0: the default)
 };
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
@@ -155,6 +156,7 @@ struct GemmArgs {
     int max_main = 0, max_slab = 0;  // most plain / slab rows any column has
     const double* Wmix = nullptr;    // [groups][Dp][Wld] ca W_atm + cr W_aer per distinct slab coefficient pair; null: two passes
     const int* mix_group = nullptr;  // [B] group of a column
+    int pad_lds = 0;                 // host side: unused dynamic LDS added to the launch (caps the workgroups per CU)
     int* live_list = nullptr;        // live-column tilings: [live_cap] the i-th live column (relative to col0), -1 beyond the live count
     int live_cap = 0;
     const int* slab_tile_group = nullptr;   // dense kernel: group of every 32-row tile of rows_slab (listed group by group, padded with -1)
@@ -189,7 +191,8 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
-                      const double* Etab, int mode, const int* erep = nullptr, int live = 0, const int* live_list = nullptr);
+                      const double* Etab, int mode, const int* erep = nullptr, int live = 0, const int* live_list = nullptr,
+                      int ring_slots = 0);
 bool transport_fast_ok(const Plan& plan);
 // erep (nullable): tables are built only for columns with erep[b] == b
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep);

@@ -46,7 +46,8 @@ __device__ __forceinline__ void wg_barrier() {
 }
 
 template <bool ACC, bool SAVED, int PIECES>
-__global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int NWL, int dbg_arg, int fixcap) {
+__global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int dbg_arg, int fixcap) {
+    constexpr int NWL = 2;                                     // loader waves
 #ifdef SOSRT_RING_DEBUG
     const int dbg = dbg_arg;            // diagnostic builds only (-DSOSRT_RING_DEBUG): timing switches that corrupt the results
 #else
@@ -79,15 +80,20 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     constexpr int IPC = NARR * TC * PIECES;                    // wave-instructions per chunk
     extern __shared__ double sm[];
     double* ring = sm;                                         // [NS][NARR][TC][RS]
-    double* s_sfc = ring + (size_t)NS * SLOT;                  // [RS] surface row by downward lane m
-    double* s_red = s_sfc + RS;                                // [nw + 1]
+    // [max(RS, coefficient tables)]: the extrapolation coefficients of each zone, compact ([zone][fixcap rewritten directions]
+    // [5 sources]), during the downward sweep; the surface row by downward lane m from the turn-round on (every wave has
+    // passed the barrier of the last downward chunk by then)
+    double* s_sfc = ring + (size_t)NS * SLOT;
+    double* s_fixc = s_sfc;
+    double* s_red = s_sfc + max(RS, kRingZones * fixcap * kFixMaxSrc);   // [nw + 1]
     double* s_hd = s_red + (blockDim.x >> 6) + 2;              // [L + 1] half layer thicknesses: hd[t] = (tau[t] - tau[t-1]) / 2
     double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
-    double* s_x = s_S + (size_t)g.nsmall * L;                  // [TC][64] rows of the wave that holds a mu -> 0 neighbourhood
-    double* s_prmu = s_x + TC * 64;                            // [16] 1/mu of the first upward directions
-    double* s_fixc = s_prmu + 16;                              // [kRingZones][fixcap][kFixMaxSrc]
-    // the extrapolation coefficients of each zone, compact ([zone][fixcap rewritten directions][5 sources]): with the ring
-    // and the row buffers a workgroup then needs less than half the LDS of a CU, so two columns share one
+    double* s_x = s_S + (size_t)g.nsmall * L;                  // [TC][16] the 16 lanes of a mu -> 0 neighbourhood, rows of a chunk
+    double* s_prmu = s_x + TC * 16;                            // [16] 1/mu of the first upward directions
+    // lanes (of the wave that holds them) of the two neighbourhoods: the last 16 downward directions, the first 16 upward ones
+    const int xb_dn = max(((N - 1) & 63) - 15, 0);
+    // (all per-column tables are compact: with the ring and the row buffers a workgroup needs less than half the LDS of a
+    // CU, so two columns share one -- or one column and two workgroups of the contraction of the other column group)
     __shared__ int s_flag[2];                                  // [0] redo with the general kernel, [1] IndexError
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
@@ -114,20 +120,26 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     };
     double rdn_v = 0, rdn_i = 1, rup_v = 0, rup_i = 1;
     double sfc_own = 0;
+    int slot_rd = 0;                                          // slot of the next chunk to read
 
     // ------------------------------- loader side -------------------------------
     // chunk q -> slot q mod NS; rows clamped at the ragged ends exactly as the computing side expects.
     // Every loader carries its share of every chunk (rows u = lid mod NWL): the loads of a chunk are
     // issued in 1/NWL of the time, and that time is on the critical path of an iteration.
+    // (a lone column is bound by the instruction streams of its waves -- a wave alone on its SIMD issues one
+    // instruction every 8 to 12 cycles and pays some 30 for a branch, tools/microbench.hip -- so the loader's
+    // iteration is straight-line code: rows by arithmetic, the ring slot by a running counter, the wait an immediate)
+    int slot_ld = 0;                                          // slot of the next chunk to issue
     auto issue = [&](int q) {
         const bool up = q >= NCH;
         const int j = up ? q - NCH : q;
-        double* dst = ring + (size_t)(q % NS) * SLOT;
+        double* dst = ring + (size_t)slot_ld * SLOT;
+        slot_ld = slot_ld + 1 == NS ? 0 : slot_ld + 1;
         const int half = up ? N * 8 : 0;
         const int vo = lane * 16;
 #pragma unroll
-        for (int u = 0; u < TC; ++u) {
-            if ((u & (NWL - 1)) != lid) continue;
+        for (int i = 0; i < TC / NWL; ++i) {
+            const int u = i * NWL + lid;
             const int row = up ? max(L - 1 - j * TC - u, 0) : min(j * TC + u, L - 1);
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) {
@@ -138,33 +150,16 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             }
         }
     };
-    // wait until at most the `w` youngest chunks are still in flight (vmcnt is an immediate: the
-    // count is rounded down to a multiple of 4, which only waits a little longer)
-    auto wait_chunks = [&](int w) {
-        const int n = min(w * (IPC / NWL), 60) >> 2;
-        switch (n) {
-            case 0: wait_vm<0>(); break;
-            case 1: wait_vm<4>(); break;
-            case 2: wait_vm<8>(); break;
-            case 3: wait_vm<12>(); break;
-            case 4: wait_vm<16>(); break;
-            case 5: wait_vm<20>(); break;
-            case 6: wait_vm<24>(); break;
-            case 7: wait_vm<28>(); break;
-            case 8: wait_vm<32>(); break;
-            case 9: wait_vm<36>(); break;
-            case 10: wait_vm<40>(); break;
-            case 11: wait_vm<44>(); break;
-            case 12: wait_vm<48>(); break;
-            case 13: wait_vm<52>(); break;
-            case 14: wait_vm<56>(); break;
-            default: wait_vm<60>(); break;
-        }
-    };
-    auto loader_phase = [&](int qa, int qb) {
+    // KEEP = vector-memory instructions of this wave that may stay in flight once chunk q+1 has landed: the R-1 younger chunks
+    auto loader_phase = [&](auto keep_t, int qa, int qb) {
+        constexpr int KEEP = decltype(keep_t)::value;
         for (int q = qa; q < qb; ++q) {
-            if (q + R < NQ && !(dbg & 16)) issue(q + R);
-            if (q + 1 < NQ) wait_chunks(min(q + R, NQ - 1) - (q + 1));      // chunk q+1 has landed
+            if (q + R < NQ) {
+                issue(q + R);
+                wait_vm<KEEP>();
+            } else {
+                wait_vm<0>();                                  // the last R iterations issue nothing: everything has to land
+            }
             wg_barrier();
         }
     };
@@ -197,17 +192,24 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     const int seam_barriers = surface == SOSRT_SURFACE_NONE ? 0 : (surface == SOSRT_SURFACE_SPECULAR ? 1 : 3);
     double Bv = 0;
     if (loader) {
-        loader_phase(0, NCH);
-        for (int i = 0; i < seam_barriers; ++i) wg_barrier();
-        loader_phase(NCH, NQ);
-        wait_vm<0>();
+        constexpr int PER = IPC / NWL;                          // instructions of one loader per chunk
+        auto run = [&](auto keep_t) {
+            loader_phase(keep_t, 0, NCH);
+            for (int i = 0; i < seam_barriers; ++i) wg_barrier();
+            loader_phase(keep_t, NCH, NQ);
+            wait_vm<0>();
+        };
+        if (R <= 1) run(std::integral_constant<int, 0>{});
+        else if (R == 2) run(std::integral_constant<int, (PER < 60 ? PER : 60)>{});
+        else if (R == 3) run(std::integral_constant<int, (2 * PER < 60 ? 2 * PER : 60)>{});
+        else run(std::integral_constant<int, (3 * PER < 60 ? 3 * PER : 60)>{});
     } else {
     stamp(1);
     const double mu_up = (valid && tid > 0) ? g.mu[N + tidc] : 1.0;   // loaded here: no global load may follow the first store
     // Transposed work items for the two mu -> 0 treatments: lane = 8 * (row of the chunk) + (position).
     const int uT = lane >> 3, pT = lane & 7;
     const double muT = (pT + 1 < N) ? g.mu[N + pT + 1] : 1.0;          // upward direction N + pT + 1
-    const double* xrow = s_x + uT * 64;
+    const double* xrow = s_x + uT * 16;
     // =============================== downward ===============================
     {
         const int m = tidc;
@@ -273,13 +275,14 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 // In_limit:113-141 as a linear map of the source lanes.  Up to 8 rewritten directions: the
                 // chunk goes through LDS and work item (uT, pT) does row uT, direction N-1-pT -- one pass for
                 // the 8 rows instead of 8 passes of cross-lane reads.
-                const bool tfix = wl && nfx > 0 && nfx <= 8;
+                const bool tfix = wl && nfx > 0 && nfx <= 8 && sl[0] >= xb_dn;   // sources inside the 16-lane window
                 if (tfix) {
 #pragma unroll
-                    for (int u = 0; u < TC; ++u) s_x[u * 64 + lane] = v[u];
+                    for (int u = 0; u < TC; ++u)
+                        if (lane >= xb_dn && lane < xb_dn + 16) s_x[u * 16 + lane - xb_dn] = v[u];
                     double acc = 0;
 #pragma unroll
-                    for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(cT[k], xrow[sl[k]], acc);
+                    for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(cT[k], xrow[max(sl[k] - xb_dn, 0)], acc);
                     const int mT = N - 1 - pT;
                     const double IcT = ACC ? slot[(2 * TC + uT) * RS + max(mT, 0)] : 0.0;
                     if (pT < nfx) {
@@ -339,7 +342,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             t0 += TC;
         };
         for (; q < NCH; ++q) {
-            const double* sp = ring + (size_t)(q % NS) * SLOT + tid;
+            const double* sp = ring + (size_t)slot_rd * SLOT + tid;
+            slot_rd = slot_rd + 1 == NS ? 0 : slot_rd + 1;
             double Jc[TC], Ic[TC], Ec[TC];
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         v[u] = tid == 0 ? Jc[u] : v[u];                  // spec:401
-                        s_x[u * 64 + lane] = v[u];
+                        if (lane < 16) s_x[u * 16 + lane] = v[u];
                     }
                     const int k = pT + 1;
                     const double xa = xrow[k], xb = xrow[k + 1], xc = xrow[k + 2];
@@ -492,7 +496,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             t0 -= TC;
         };
         for (; q < NQ; ++q) {
-            const double* sp = ring + (size_t)(q % NS) * SLOT + tid;
+            const double* sp = ring + (size_t)slot_rd * SLOT + tid;
+            slot_rd = slot_rd + 1 == NS ? 0 : slot_rd + 1;
             double Jc[TC], Ic[TC], Ec[TC];
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         // row, the row exchanged through LDS so that every direction can be a candidate.  Rare (never in the sweeps of the
         // bench), so written for size, not speed; it replaces the separate repair launch after every order.  The rows the
         // fast path stored are read back past the L1 to correct the running total: I += new - old.
-        double* s_row = s_x;                                            // [N]
+        double* s_row = ring;                                           // [N] (the ring is free by now)
         int& s_kf = *reinterpret_cast<int*>(s_red);                    // (the reduction slots are free here; no more static LDS:
         const bool act = tid < N;                                       //  two workgroups must keep fitting a CU)
         const int j = act ? tid : 0;
@@ -597,12 +602,12 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 // rewritten directions the compact coefficient tables hold: the largest int(c N) of In_limit / I1_In:124-127
 inline int ring_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
 inline size_t ring_extra_doubles(const Grid& g, int nt) {
-    const int rs = g.N <= 128 ? 128 : 256;
-    return (size_t)rs + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 64 + 16 + (size_t)kRingZones * ring_fixcap(g) * kFixMaxSrc;
+    const int rs = g.N <= 128 ? 128 : 256, fc = kRingZones * ring_fixcap(g) * kFixMaxSrc;
+    return (size_t)(rs > fc ? rs : fc) + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 16 + 16;
 }
 
 template <int PIECES>
-void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int NS, int NWL) {
+void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int NS) {
     const int nt = (int)block.x;
     const int narr = a.accumulate ? 3 : 2;
     const size_t shm = ((size_t)NS * narr * TC * 128 * PIECES + ring_extra_doubles(a.g, nt)) * sizeof(double);
@@ -615,7 +620,7 @@ void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int 
                                 (int)kRingLdsBytes);                                                                   \
             big_lds = true;                                                                                    \
         }                                                                                                      \
-        hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, NWL, g_ring_debug, ring_fixcap(a.g));                           \
+        hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, g_ring_debug, ring_fixcap(a.g));                           \
     } while (0)
     if (a.accumulate) {
         if (a.saved) SOSRT_RING_LAUNCH(true, true);
@@ -639,19 +644,19 @@ bool transport_ring_ok(const Grid& g) {
 
 // slots: ring depth wanted (2..6); loaders: loader waves per column
 void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots, int loaders) {
+    if (a.slots > 0) slots = a.slots;
     const int N = a.g.N;
     const int nwc = (N + 63) / 64;
     const int pieces = N <= 128 ? 1 : 2;
     const int narr = a.accumulate ? 3 : 2;
-    int NWL = (loaders == 1 || loaders == 2 || loaders == 4) ? loaders : 2;      // a power of two that divides TC
-    if ((nwc + NWL) * 64 > 512) NWL = 2;
-    const dim3 block((nwc + NWL) * 64);
+    (void)loaders;                                                               // two loader waves (compile-time in the kernel)
+    const dim3 block((nwc + 2) * 64);
     const size_t slot_bytes = (size_t)narr * TC * 128 * pieces * sizeof(double);
     const size_t extra = ring_extra_doubles(a.g, (int)block.x) * sizeof(double);
     int NS = slots < 2 ? 2 : slots;
     while (NS > 2 && NS * slot_bytes + extra > kRingLdsBytes) --NS;
-    if (pieces == 1) launch_p<1>(s, grid, block, a, NS, NWL);
-    else launch_p<2>(s, grid, block, a, NS, NWL);
+    if (pieces == 1) launch_p<1>(s, grid, block, a, NS);
+    else launch_p<2>(s, grid, block, a, NS);
 }
 
 }  // namespace sosrt
