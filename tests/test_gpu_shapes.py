@@ -269,6 +269,33 @@ def test_sharded_solve_equals_single_rank_bit_for_bit():
     assert np.array_equal(sub.I, one.I[:5])
 
 
+def test_two_column_groups_on_two_streams_are_bit_identical(monkeypatch):
+    """SOSRT_GROUPS=2: the order loop runs per half of the batch, the second half on an internal stream, contraction and
+    transport of the two halves side by side on the CUs (capped contraction occupancy, two-slot ring).  Same bits as
+    the single-group loop -- and the tilings differ, so this is also a batch-invariance check."""
+    from sosrt import main as M
+    rng = np.random.default_rng(11)
+    B = 600
+    mu0 = rng.uniform(0.2, 1.0, B)
+    taer = rng.choice([0.02, 0.12, 0.6], B)
+    rho = rng.uniform(0.0, 0.8, B)
+    kw = dict(tauStar_atm=0.124, alb_aer=0.9, nb_layers=40, nb_angles=64, max_orders=200)
+    out = []
+    for groups in ("1", "2"):
+        monkeypatch.setenv("SOSRT_GROUPS", groups)
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+        out.append(SOS_Aer_batch(mu0, taer, rho, **kw))
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    a, b = out
+    assert (a.status == 0).all()
+    assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
+    assert np.array_equal(a.I, b.I)                         # bit for bit
+
+
 def test_reference_shipped_size_L800_N501():
     """The size the reference ships (spec:33,57: nb_layers = 800, nb_angles = 501 -- odd and > 256, so the
     register-streaming transport kernel and the N >= 501 extrapolation tables) against the oracle, one column, at
