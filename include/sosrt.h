@@ -80,6 +80,16 @@ int sosrt_set_grid(sosrt_t* h, const double* mu);
  * single-slab geometry.  Folded on the host into W[k][m] = w_k P[m][2N-1-k] (I1_In:73, spec:321). */
 int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer);
 
+/* First order of the solve.  CODED (default): spec:104-292 -- what both mains of the reference compute, with the specularly
+ * reflected beam (SOS_Aer_main_lambertian.py's first-order blocks are the same formulas; its lines 274-276 crash).
+ * README: the Lambertian first order of the reference's README.md:126-171 -- direct beam + the beam reflected isotropically by
+ * the ground (int_0^1 mu'/(mu'-mu) ... dmu' by the trapezoid rule on the upward directions, the removable singularity at
+ * mu' = mu taken analytically) + isotropic reflection of the downward first order.  PARITY UNPINNED: no runnable reference
+ * code exists for it.  Meant for SOSRT_SURFACE_LAMBERTIAN_README; three-zone geometry only. */
+#define SOSRT_FIRST_ORDER_CODED 0
+#define SOSRT_FIRST_ORDER_README 1
+int sosrt_set_first_order(sosrt_t* h, int mode);
+
 /* arithmetic of the source-function contraction (BASELINE configs[4]: "fp64 -> fp32 mixed with tolerance study").
  * SOSRT_CONTRACT_F64 (default): v_mfma_f64_16x16x4_f64 -- the only mode that meets the 1e-10 parity bar.
  * SOSRT_CONTRACT_F32: operands rounded to float, v_mfma_f32_16x16x4_f32 with a float accumulator; transport, running

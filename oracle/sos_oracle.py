@@ -244,6 +244,7 @@ class Column:
     # has one slab only, so more than one is PARITY UNPINNED by construction; with the three zones of the reference the
     # table path is the same arithmetic (checked bit for bit in tests/test_oracle_golden.py).
     zone_table: Optional[List[_Zone]] = None
+    first_order: str = "coded"     # 'coded' (spec:104-292, what both mains compute) | 'readme' (README.md:126-171, Lambertian; unpinned)
 
     @property
     def zones(self) -> List[_Zone]:
@@ -367,6 +368,92 @@ def first_order(c: Column) -> np.ndarray:
     return I1
 
 
+def first_order_lambertian_readme(c: Column) -> np.ndarray:
+    """First order over a Lambertian surface as the reference's README writes it (README.md:126-171).  PARITY UNPINNED: the
+    reference ships no runnable code for it -- `lam:274-276` crashes and the other first-order blocks of that
+    file are the specular-beam formulas.  Non-default option (`first_order='readme'`).
+
+    Per zone and direction: attenuated boundary row + single scattering of the direct beam (the reference's own
+    `scatt_direct`, spec:113-292) + single scattering of the direct beam reflected isotropically by the ground,
+
+        int_0^1  mu'/(mu'-mu)  omega P(mu,-mu')/(4 pi)  2 rho F0 e^{-T/mu0}  ( e^{-(T-tau)/mu'} - e^{-(T-tau_b)/mu'} e^{-|tau-tau_b|/|mu|} ) dmu'
+
+    by the trapezoid rule on the upward half of the direction grid (the grid the reference integrates on everywhere),
+    with the README's constant as written.  The integrand's removable singularity at mu' = mu (upward directions lie on
+    the quadrature nodes) is replaced by its limit  omega P/(4 pi) 2 rho F0 e^{-T/mu0} e^{-(T-tau)/mu} (tau_b-tau)/mu.
+    `tau_b` is the level the zone is entered at (the row above going down, the row below -- the surface row for the bottom
+    zone -- going up), the same level for the beam and the surface term.  Upward boundary at the ground: isotropic
+    2 rho int_0^1 I1_down(T, -mu') mu' dmu' (README.md:151, taken positive as in README.md:215)."""
+    tau, mu, N, mu0 = c.tau, c.mu, c.N, c.mu0
+    L = len(tau)
+    F0 = np.pi / mu0
+    T = c.tauStar_tot
+    R2 = 2 * c.grd_alb * F0 * np.exp(-T / mu0)
+    mirror = 2 * N - 1 - np.arange(2 * N)
+    mup = mu[N:]                                   # quadrature nodes mu' = 0 .. 1
+    wq = np.zeros(N)                               # trapezoid weights on them
+    wq[:-1] += np.diff(mup) / 2
+    wq[1:] += np.diff(mup) / 2
+
+    def q_of(z):
+        if z.kind != "mix":
+            return c.alb_atm * c.P0_atm / (4 * np.pi), c.alb_atm * c.P_atm / (4 * np.pi)
+        fa, fr = c.zone_fractions(z)
+        return ((c.alb_atm * c.P0_atm * fa + z.alb_aer * c.P0_aer * fr) / (4 * np.pi),
+                (c.alb_atm * c.P_atm * fa + z.alb_aer * c.P_aer * fr) / (4 * np.pi))
+    I1 = np.zeros((L, 2 * N))
+    zones = c.zones
+    with np.errstate(all="ignore"):
+        md = mu[:N - 1]
+        near_d = np.abs(md + mu0) < 0.0001
+        for zi, z in enumerate(zones):
+            q, Q = q_of(z)
+            Qk = Q[:, mirror[N:]]                  # radiation travelling along +mu'_k scattered into direction m (Jn's convention)
+            t_b = 0.0 if zi == 0 else tau[z.r0 - 1]
+            for t in range(z.r0, z.r1 + 1):
+                att = np.exp((tau[t] - t_b) / md)
+                before = 0.0 if zi == 0 else I1[z.r0 - 1, :N - 1] * att
+                direct = (mu0 / (mu0 + md)) * q[:N - 1] * F0 * (np.exp(-tau[t] / mu0) - np.exp(-t_b / mu0) * att)
+                direct_near = q[:N - 1] * F0 * np.exp(-tau[t] / mu0) * (tau[t] - t_b) / mu0
+                e1 = np.where(mup > 0, np.exp(-(T - tau[t]) / np.where(mup > 0, mup, 1.0)), 0.0)
+                e2 = np.where(mup > 0, np.exp(-(T - t_b) / np.where(mup > 0, mup, 1.0)), 0.0)
+                ker = mup[None, :] / (mup[None, :] - md[:, None])                       # mu' - mu > 0 for downward mu
+                lam = (wq[None, :] * ker * Qk[:N - 1] * (e1[None, :] - e2[None, :] * att[:, None])).sum(axis=1) * R2
+                I1[t, :N - 1] = before + np.where(near_d, direct_near, direct) + lam
+                # mu = 0-: the second exponential vanishes, mu'/(mu'-mu) = 1
+                I1[t, N - 1] = q[N - 1] * F0 * np.exp(-tau[t] / mu0) + (wq * Qk[N - 1] * e1).sum() * R2
+        mp = mu[N + 1:]
+        for zi in range(len(zones) - 1, -1, -1):
+            z = zones[zi]
+            q, Q = q_of(z)
+            Qk = Q[:, mirror[N:]]
+            bottom = zi == len(zones) - 1
+            if bottom:
+                t_b = tau[L - 1]
+                w_dn = np.zeros(N)
+                w_dn[:-1] += np.diff(mu[:N]) / 2
+                w_dn[1:] += np.diff(mu[:N]) / 2
+                B = 2 * c.grd_alb * (w_dn * I1[L - 1, :N] * (-mu[:N])).sum() * np.ones(N - 1)
+            else:
+                t_b = tau[z.r1 + 1]
+            for t in range(z.r0, z.r1 + 1):
+                if not bottom:
+                    B = I1[z.r1 + 1, N + 1:]
+                att = np.exp(-(t_b - tau[t]) / mp)
+                direct = (mu0 / (mu0 + mp)) * q[N + 1:] * F0 * (np.exp(-tau[t] / mu0) - np.exp(-t_b / mu0) * att)
+                e1 = np.where(mup > 0, np.exp(-(T - tau[t]) / np.where(mup > 0, mup, 1.0)), 0.0)
+                e2 = np.where(mup > 0, np.exp(-(T - t_b) / np.where(mup > 0, mup, 1.0)), 0.0)
+                diff = mup[None, :] - mp[:, None]
+                same = np.abs(diff) < 0.0001                                            # the node mu' = mu itself
+                ker = mup[None, :] / np.where(same, 1.0, diff)
+                term = ker * (e1[None, :] - e2[None, :] * att[:, None])
+                lim = (np.exp(-(T - tau[t]) / mp) * (t_b - tau[t]) / mp)[:, None]
+                lam = (wq[None, :] * Qk[N + 1:] * np.where(same, lim, term)).sum(axis=1) * R2
+                I1[t, N + 1:] = B * att + direct + lam
+                I1[t, N] = q[N] * F0 * np.exp(-tau[t] / mu0) + (wq * Qk[N] * e1).sum() * R2
+    return I1
+
+
 def source_function(c: Column, In_1: np.ndarray) -> np.ndarray:
     """Three-zone Jn, spec:314-323."""
     L = len(c.tau)
@@ -486,7 +573,7 @@ def solve_column(c: Column, tol: float = 1e-4, max_orders: int = 10000, literal:
                  I1: Optional[np.ndarray] = None) -> Solution:
     """The order loop of spec:301-458."""
     if I1 is None:
-        I1 = first_order(c)
+        I1 = first_order_lambertian_readme(c) if c.first_order == "readme" else first_order(c)
     In_1 = I1
     I = I1.copy()
     saved = [I1]

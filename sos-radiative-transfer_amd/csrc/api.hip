@@ -80,6 +80,7 @@ struct sosrt_handle {
     // device: grid / phase
     double *d_mu = nullptr, *d_Wa = nullptr, *d_Wr = nullptr, *d_wfdn = nullptr, *d_wfup = nullptr;
     double *d_w = nullptr;               // [D] np.trapz weights on the whole grid
+    int first_order_mode = SOSRT_FIRST_ORDER_CODED;   // sosrt_set_first_order
     double *d_phi = nullptr;             // [2][kNPhi] cos(phi), trapz weights of phi = linspace(0, pi, kNPhi) (phase:81-82)
     double *d_z = nullptr;               // [L] altitude grid of the host epilogue
     double *d_tab = nullptr;             // [2][ntab] table of SOSRT_PHASE_TABLE
@@ -481,6 +482,15 @@ int sosrt_set_saved_orders(sosrt_t* h, int slots) {
     return 0;
 }
 
+int sosrt_set_first_order(sosrt_t* h, int mode) {
+    if (int e = need_gpu(h)) return e;
+    if (mode != SOSRT_FIRST_ORDER_CODED && mode != SOSRT_FIRST_ORDER_README) return fail(SOSRT_E_INVALID, "unknown first-order mode %d", mode);
+    if (mode == SOSRT_FIRST_ORDER_README && h->geom != SOSRT_GEOM_THREE_ZONE)
+        return fail(SOSRT_E_INVALID, "the README's Lambertian first order needs the three-zone geometry (it has a surface)");
+    h->first_order_mode = mode;
+    return 0;
+}
+
 int sosrt_set_contraction(sosrt_t* h, int mode) {
     if (int e = need_gpu(h)) return e;
     if (mode != SOSRT_CONTRACT_F64 && mode != SOSRT_CONTRACT_F32) return fail(SOSRT_E_INVALID, "unknown contraction mode %d", mode);
@@ -777,8 +787,12 @@ int sosrt_first_order(sosrt_t* h, int B, const double* tau, const double* P0_atm
     if (P0_aer) HIPCHK(hipMemcpyAsync(h->d_P0r, P0_aer, (size_t)B * h->D * sizeof(double), hipMemcpyHostToDevice, h->stream));
     launch_prepare(h->stream, h->g, B, h->geom, h->surface, scalars_of(h), h->d_tau, h->d_desc, h->d_rca, h->d_rcr);
     prof_begin(h, SOSRT_K_FIRST);
-    launch_first_order(h->stream, h->g, B, h->d_tau, h->d_P0a, P0_aer ? h->d_P0r : nullptr, h->d_desc, h->d_InA, nullptr,
-                       nullptr, 0, make_conv(h, 0), 0);
+    if (h->first_order_mode == SOSRT_FIRST_ORDER_README)
+        launch_first_order_readme(h->stream, h->g, h->d_w, B, h->d_tau, h->d_P0a, P0_aer ? h->d_P0r : nullptr, h->d_desc, h->d_InA,
+                                  nullptr, nullptr, 0, make_conv(h, 0), 0);
+    else
+        launch_first_order(h->stream, h->g, B, h->d_tau, h->d_P0a, P0_aer ? h->d_P0r : nullptr, h->d_desc, h->d_InA, nullptr,
+                           nullptr, 0, make_conv(h, 0), 0);
     prof_end(h, SOSRT_K_FIRST);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(I1_out, h->d_InA, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -938,6 +952,11 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         if (d_I1_in)
             hipLaunchKernelGGL(k_init_from_I1, dim3(q.nb), dim3(256), 0, sg, g, d_I1_in + fo, q.In_1 + fo, d_I_out + fo,
                                d_I_saved_out ? d_I_saved_out + (size_t)q.b0 * saved_stride : nullptr, saved_stride, q.cv);
+        else if (h->first_order_mode == SOSRT_FIRST_ORDER_README)
+            launch_first_order_readme(sg, g, h->d_w, q.nb, d_tau + (size_t)q.b0 * h->L, d_P0_atm + (size_t)q.b0 * g.D,
+                                      d_P0_aer ? d_P0_aer + (size_t)q.b0 * g.D : nullptr, h->d_desc + q.b0, q.In_1 + fo,
+                                      d_I_out + fo, d_I_saved_out ? d_I_saved_out + (size_t)q.b0 * saved_stride : nullptr,
+                                      saved_stride, q.cv, 1);
         else
             launch_first_order(sg, g, q.nb, d_tau + (size_t)q.b0 * h->L, d_P0_atm + (size_t)q.b0 * g.D,
                                d_P0_aer ? d_P0_aer + (size_t)q.b0 * g.D : nullptr, h->d_desc + q.b0, q.In_1 + fo, d_I_out + fo,

@@ -320,7 +320,214 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_first_order_readme: the first order over a Lambertian surface as the reference's README writes it
+// (README.md:126-171) -- a non-default option, PARITY UNPINNED: the reference has no runnable code for it (lam:274-276
+// crashes; its other first-order blocks are the specular-beam ones above).  Per zone and direction:
+// attenuated boundary row + scattering of the direct beam (as above) + scattering of the direct beam reflected
+// isotropically by the ground,
+//     int_0^1 mu'/(mu'-mu) omega P(mu,-mu')/(4 pi) 2 rho F0 e^{-T/mu0} (e^{-(T-tau)/mu'} - e^{-(T-tau_b)/mu'} e^{-|tau-tau_b|/|mu|}) dmu'
+// by the trapezoid rule on the upward half of the direction grid; w_k P[m][2N-1-k] is the row k of the contraction
+// matrices (the weights of the whole grid and of its upward half agree on that half).  The removable singularity at
+// mu' = mu is replaced by its limit.  tau_b: the level a zone is entered at.  Ground: isotropic reflection of the
+// downward first order (README.md:151 with the sign of README.md:215).  One workgroup per column, thread j = downward
+// direction j, then upward direction N + j; FU rows at a time, their e^{-(T-tau)/mu'} shared through LDS.
+// ------------------------------------------------------------------------------------------
+__global__ void k_first_order_readme(Grid g, const double* __restrict__ w_all, const double* __restrict__ tau_all,
+                                     const double* __restrict__ P0a_all, const double* __restrict__ P0r_all,
+                                     const ColDesc* __restrict__ desc, double* __restrict__ I1_all, double* __restrict__ I_all,
+                                     double* __restrict__ saved, size_t saved_col_stride, Conv cv, int do_conv) {
+    constexpr int FU = 4;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int L = g.L, N = g.N, D = g.D, Wld = g.Wld;
+    extern __shared__ double sm[];
+    double* s_tau = sm;                      // [L]
+    double* s_e0 = s_tau + L;                // [L] exp(-tau/mu0)
+    double* s_mup = s_e0 + L;                // [N] quadrature nodes mu' = mu[N + k]
+    double* s_e2 = s_mup + N;                // [N] exp(-(T - tau_b)/mu')
+    double* s_e1 = s_e2 + N;                 // [FU][N] exp(-(T - tau_t)/mu') of the rows of a pass
+    double* s_red = s_e1 + FU * N;           // [nw + 2]
+    __shared__ ColDesc d;
+    if (tid == 0) d = desc[b];
+    const double* tau = tau_all + (size_t)b * L;
+    const double* P0a = P0a_all + (size_t)b * D;
+    const double* P0r = P0r_all ? P0r_all + (size_t)b * D : P0a;
+    double* I1 = I1_all + (size_t)b * L * D;
+    double* Iacc = I_all ? I_all + (size_t)b * L * D : nullptr;
+    double* sv = saved ? saved + (size_t)b * saved_col_stride : nullptr;
+    for (int t = tid; t < L; t += blockDim.x) s_tau[t] = tau[t];
+    for (int k = tid; k < N; k += blockDim.x) s_mup[k] = g.mu[N + k];
+    __syncthreads();
+    const double mu0 = d.mu0, T = d.T, rho = d.rho;
+    const double F0 = SOSRT_PI / mu0;
+    const double R2 = 2 * rho * F0 * exp(-T / mu0);
+    const double c4pi = 1.0 / (4 * SOSRT_PI);
+    const bool valid = tid < N;
+    for (int t = tid; t < L; t += blockDim.x) s_e0[t] = exp(-s_tau[t] / mu0);
+    __syncthreads();
+    auto store = [&](int t, int m, double v) {
+        I1[(size_t)t * D + m] = v;
+        if (Iacc) Iacc[(size_t)t * D + m] = v;
+        if (sv) sv[(size_t)t * D + m] = v;
+    };
+    // exponentials of the quadrature nodes: one zone level, or the rows of a pass (mu' = 0: nothing arrives)
+    auto fill_e2 = [&](double t_b) {
+        __syncthreads();
+        for (int k = tid; k < N; k += blockDim.x) s_e2[k] = s_mup[k] > 0 ? exp(-(T - t_b) / s_mup[k]) : 0.0;
+    };
+    auto fill_e1 = [&](int tb, int step, int lo, int hi) {
+        __syncthreads();
+        for (int i = tid; i < FU * N; i += blockDim.x) {
+            const int u = i / N, k = i - u * N;
+            const int t = min(max(tb + step * u, lo), hi);
+            s_e1[i] = s_mup[k] > 0 ? exp(-(T - s_tau[t]) / s_mup[k]) : 0.0;
+        }
+        __syncthreads();
+    };
+    double rdn = 0, rup = 0;
+    double sfc = 0;                                          // I1[L-1][m] of this thread's downward direction
+
+    // ---- downward, m = tid ----
+    {
+        const int m = valid ? tid : 0;
+        const double mu = g.mu[m];
+        const double pa = P0a[m], pr = P0r[m];
+        const bool near = fabs(mu + mu0) < 0.0001;
+        const bool node = m > N - 2;                         // mu = 0-
+        const double gd = mu0 / (mu0 + mu);
+        double Ib = 0, vlast = 0;
+        for (int z = 0; z < d.nz; ++z) {
+            const double ca = d.wa * (d.mix[z] ? d.fa[z] : 1.0) * c4pi, cr = d.mix[z] ? d.wr[z] * d.fr[z] * c4pi : 0.0;
+            const double q = ca * pa + cr * pr;
+            const double t_b = z ? s_tau[d.r0[z] - 1] : 0.0;
+            const double e_b = exp(-t_b / mu0);
+            fill_e2(t_b);
+            const int r0 = d.r0[z], r1 = d.r1[z];
+            for (int tb = r0; tb <= r1; tb += FU) {
+                fill_e1(tb, 1, r0, r1);
+                double att[FU], acc[FU];
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    att[u] = node ? 0.0 : exp((s_tau[min(tb + u, r1)] - t_b) / mu);
+                    acc[u] = 0;
+                }
+                for (int k = 0; k < N; ++k) {
+                    const size_t wi = (size_t)(N + k) * Wld + m;
+                    const double Qk = ca * g.Wa[wi] + (cr != 0.0 ? cr * g.Wr[wi] : 0.0);
+                    const double mk = s_mup[k];
+                    const double ker = node ? 1.0 : mk / (mk - mu);
+                    const double e2 = s_e2[k];
+#pragma unroll
+                    for (int u = 0; u < FU; ++u) acc[u] += Qk * ker * (s_e1[u * N + k] - e2 * att[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int t = tb + u;
+                    if (t <= r1) {
+                        const double tt = s_tau[t], e0 = s_e0[t];
+                        const double before = z ? Ib * att[u] : 0.0;
+                        const double direct = near ? q * F0 * e0 * (tt - t_b) / mu0 : gd * q * F0 * (e0 - e_b * att[u]);
+                        const double v = node ? q * F0 * e0 + acc[u] * R2 : before + direct + acc[u] * R2;
+                        if (valid) store(t, m, v);
+                        vlast = v;
+                    }
+                }
+            }
+            Ib = vlast;
+        }
+        sfc = vlast;
+        rdn = 1.0 / vlast;
+    }
+    // ---- ground: 2 rho int_0^1 I1_down(T, -mu') mu' dmu', isotropic ----
+    double Bsfc;
+    {
+        const double term = valid ? w_all[tid] * sfc * (-g.mu[tid]) : 0.0;
+        double v = term;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = v;
+        __syncthreads();
+        double S = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) S += s_red[i];
+        Bsfc = 2 * rho * S;
+    }
+    // ---- upward, m = N + tid, zones bottom to top ----
+    {
+        const int j = valid ? tid : 0, m = N + j;
+        const double mu = g.mu[m];
+        const double pa = P0a[m], pr = P0r[m];
+        const bool node = j < 1;                             // mu = 0+
+        const double gd = mu0 / (mu0 + mu);
+        double Bv = Bsfc, vlast = 0;
+        for (int z = d.nz - 1; z >= 0; --z) {
+            const bool bottom = z == d.nz - 1;
+            const double ca = d.wa * (d.mix[z] ? d.fa[z] : 1.0) * c4pi, cr = d.mix[z] ? d.wr[z] * d.fr[z] * c4pi : 0.0;
+            const double q = ca * pa + cr * pr;
+            const double t_b = bottom ? s_tau[L - 1] : s_tau[d.r1[z] + 1];
+            const double e_b = exp(-t_b / mu0);
+            fill_e2(t_b);
+            const int r0 = d.r0[z], r1 = d.r1[z];
+            for (int tb = r1; tb >= r0; tb -= FU) {
+                fill_e1(tb, -1, r0, r1);
+                double att[FU], acc[FU], lim[FU];
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const double tt = s_tau[max(tb - u, r0)];
+                    att[u] = node ? 0.0 : exp(-(t_b - tt) / mu);
+                    lim[u] = node ? 0.0 : exp(-(T - tt) / mu) * (t_b - tt) / mu;
+                    acc[u] = 0;
+                }
+                for (int k = 0; k < N; ++k) {
+                    const size_t wi = (size_t)(N + k) * Wld + m;
+                    const double Qk = ca * g.Wa[wi] + (cr != 0.0 ? cr * g.Wr[wi] : 0.0);
+                    const double mk = s_mup[k];
+                    const bool same = !node && fabs(mk - mu) < 0.0001;           // the node mu' = mu itself
+                    const double ker = node ? 1.0 : mk / (same ? 1.0 : mk - mu);
+                    const double e2 = s_e2[k];
+#pragma unroll
+                    for (int u = 0; u < FU; ++u) acc[u] += Qk * (same ? lim[u] : ker * (s_e1[u * N + k] - e2 * att[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    const int t = tb - u;
+                    if (t >= r0) {
+                        const double e0 = s_e0[t];
+                        const double v = node ? q * F0 * e0 + acc[u] * R2 : Bv * att[u] + gd * q * F0 * (e0 - e_b * att[u]) + acc[u] * R2;
+                        if (valid) store(t, m, v);
+                        vlast = v;
+                    }
+                }
+            }
+            Bv = vlast;
+        }
+        rup = 1.0 / vlast;
+    }
+    if (do_conv) {
+        const double a = block_pymax(rup, valid, s_red);
+        const double bb = block_pymax(rdn, valid, s_red);
+        const double r = outer_pymax(a, bb);
+        if (tid == 0) {
+            cv.ratio[b] = r;
+            cv.norders[b] = 1;
+            cv.status[b] = SOSRT_COL_OK;
+            const int go = (r >= cv.tol) ? 1 : 0;
+            cv.active[b] = go;
+            if (go) atomicAdd(cv.nactive, 1);
+        }
+    }
+}
+
 static int round64(int n) { return (n + 63) / 64 * 64; }
+
+void launch_first_order_readme(hipStream_t s, const Grid& g, const double* w, int B, const double* tau, const double* P0a,
+                               const double* P0r, const ColDesc* desc, double* I1_out, double* I_out, double* saved,
+                               size_t saved_col_stride, Conv cv, int do_conv) {
+    const int nt = round64(g.N);
+    const size_t shm = (size_t)(2 * g.L + 2 * g.N + 4 * g.N + nt / 64 + 4) * sizeof(double);
+    hipLaunchKernelGGL(k_first_order_readme, dim3(B), dim3(nt), shm, s, g, w, tau, P0a, P0r, desc, I1_out, I_out, saved,
+                       saved_col_stride, cv, do_conv);
+}
 
 void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, const double* P0a, const double* P0r,
                         const ColDesc* desc, double* I1_out, double* I_out, double* saved, size_t saved_col_stride,

@@ -128,6 +128,9 @@ extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_sta
 
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
                     ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small = nullptr);
+void launch_first_order_readme(hipStream_t s, const Grid& g, const double* w, int B, const double* tau, const double* P0a,
+                               const double* P0r, const ColDesc* desc, double* I1_out, double* I_out, double* saved,
+                               size_t saved_col_stride, Conv cv, int do_conv);
 void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, const double* P0a, const double* P0r,
                         const ColDesc* desc, double* I1_out, double* I_out, double* saved, size_t saved_col_stride,
                         Conv cv, int do_conv);

@@ -73,14 +73,17 @@ def _raise_status(status, nb_angles):
 def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, alb_aer=1.0, z0=120, z_up=25, z_down=17,
                   nb_layers=200, nb_angles=128, atm_phase_fun="rayleigh", g_atm=0.0, aer_phase_fun="hg", g_aer=0.7,
                   P_atm=None, P_aer=None, P0_atm=None, P0_aer=None, surface="specular", tol=1e-4, max_orders=256,
-                  save_orders=False, device=0, devices=None, raise_on_error=True) -> BatchResult:
+                  save_orders=False, device=0, devices=None, raise_on_error=True, first_order="coded") -> BatchResult:
     """Solve B independent columns (arrays mu0, tauStar_aer, grd_alb broadcast to a common length;
-    tauStar_atm, alb_atm, alb_aer may be arrays too).  `devices=[0, 1, ...]` shards the columns over several
+    tauStar_atm, alb_atm, alb_aer may be arrays too).  `first_order='readme'`: the README's Lambertian first order
+    (Solver.set_first_order; parity unpinned, single device).  `devices=[0, 1, ...]` shards the columns over several
     GPUs of the node, one worker process each, and gathers the fields (sosrt.dist.solve_on_devices; per-order
     fields are not gathered)."""
     if devices is not None and len(devices) > 1:
         if save_orders:
             raise ValueError("save_orders is not available with devices=[...]")
+        if first_order != "coded":
+            raise ValueError("first_order='readme' is not available with devices=[...]")
         from .dist import solve_on_devices
         r = solve_on_devices(devices, mu0, tauStar_aer, grd_alb, tauStar_atm=tauStar_atm, alb_atm=alb_atm, alb_aer=alb_aer,
                              z0=z0, z_up=z_up, z_down=z_down, nb_layers=nb_layers, nb_angles=nb_angles,
@@ -125,7 +128,11 @@ def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, 
         s.set_phase(P_atm, P_aer)
     s.set_columns(np.full(B, iu), np.full(B, idn), mu0, grd_alb, alb_atm, alb_aer,
                   tauStar_atm / L, tauStar_aer / (idn + 1 - iu), tauStar_atm + tauStar_aer, surface=surface)
-    r = s.solve(tau, P0a, P0r, tol=tol, save_orders=save_orders)
+    s.set_first_order(first_order)
+    try:
+        r = s.solve(tau, P0a, P0r, tol=tol, save_orders=save_orders)
+    finally:
+        s.set_first_order("coded")                           # (the solver is cached)
     if raise_on_error:
         _raise_status(r.status, N)
     return BatchResult(I=r.I, n=r.n, status=r.status, tau=tau, mu=mu, idx_up=iu, idx_down=idn, I_saved=r.I_saved)
@@ -173,7 +180,7 @@ def SOS_Aer_layers(mu0, grd_alb, slabs, *, tauStar_atm=0.124, alb_atm=1.0, z0=12
 
 
 def SOS_Aer(surface="specular", tol=1e-4, max_orders=256, P_atm=None, P0_atm=None, P_aer=None, P0_aer=None, device=0,
-            **overrides) -> ColumnResult:
+            first_order="coded", **overrides) -> ColumnResult:
     """One column with the reference's parameter names (spec:19-96).  `surface` selects the file of
     the reference that would be run ('specular' | 'lambertian'); P*/P0* accept pre-built phase
     arrays."""
@@ -192,7 +199,7 @@ def SOS_Aer(surface="specular", tol=1e-4, max_orders=256, P_atm=None, P0_atm=Non
     r = SOS_Aer_batch(p["mu0"], p["tauStar_aer"], p["grd_alb"], tauStar_atm=p["tauStar_atm"], alb_atm=p["alb_atm"],
                       alb_aer=p["alb_aer"], z0=p["z0"], z_up=p["z_up"], z_down=p["z_down"], nb_layers=L, nb_angles=N,
                       P_atm=P_atm, P_aer=P_aer, P0_atm=np.asarray(P0_atm)[None], P0_aer=np.asarray(P0_aer)[None],
-                      surface=surface, tol=tol, max_orders=max_orders, save_orders=True, device=device)
+                      surface=surface, tol=tol, max_orders=max_orders, save_orders=True, device=device, first_order=first_order)
     n = int(r.n[0])
     return ColumnResult(I=r.I[0], I_saved=r.I_saved[0, :n].copy(), n=n, tau=r.tau[0], mu=r.mu, idx_up=r.idx_up,
                         idx_down=r.idx_down, status=int(r.status[0]))

@@ -82,6 +82,16 @@ class Solver:
             raise ValueError("contraction must be 'f64' or 'f32'")
         check(lib().sosrt_set_contraction(self._h, m))
 
+    def set_first_order(self, mode="coded"):
+        """'coded' (default): spec:104-292, what both mains of the reference compute (specularly reflected beam).
+        'readme': the Lambertian first order of the reference's README.md:126-171 (direct beam + the beam reflected
+        isotropically by the ground + isotropic reflection of the downward first order) -- PARITY UNPINNED, the
+        reference has no runnable code for it; meant for surface='lambertian_readme', after set_columns."""
+        m = {"coded": _lib.FIRST_ORDER_CODED, "readme": _lib.FIRST_ORDER_README}.get(mode)
+        if m is None:
+            raise ValueError("first_order must be 'coded' or 'readme'")
+        check(lib().sosrt_set_first_order(self._h, m))
+
     def set_grid(self, mu):
         mu = _f64(mu, (self.D,), "mu")
         check(lib().sosrt_set_grid(self._h, _ptr(mu)))

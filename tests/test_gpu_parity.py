@@ -320,3 +320,35 @@ def test_mixed_slab_geometries_and_shared_profiles_in_one_batch(transport_mode):
         assert r.n[b] == ref.n, (b, r.n[b], ref.n)
         assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
 
+
+
+# ----------------------------------------------------------------------------------------------
+# the README's Lambertian first order (non-default option; PARITY UNPINNED -- SURVEY H1: the reference has no runnable
+# code for it).  Device against the oracle's restatement of README.md:126-171, and two properties.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,N,rho,taer", [(50, 32, 0.15, 0.3), (200, 128, 0.3, 0.12), (64, 48, 0.05, 0.6)])
+def test_readme_lambertian_first_order(L, N, rho, taer):
+    mu = inputs.direction_grid(N)
+    mu0 = 0.6
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, mu0)
+    P0r, Pr = inputs.phase_function("hg", N, mu, mu0, 0.7)
+    col = O.make_column(mu0, 120, 25, 17, L, 0.124, taer, rho, 1.0, 0.9, N, P0a, Pa, P0r, Pr, surface="lambertian_readme")
+    col.first_order = "readme"
+    ref1 = O.first_order_lambertian_readme(col)
+    kw = dict(mu0=mu0, tauStar_aer=taer, grd_alb=rho, tauStar_atm=0.124, alb_atm=1.0, alb_aer=0.9, z0=120, z_up=25, z_down=17,
+              nb_layers=L, nb_angles=N)
+    r = SOS_Aer("lambertian_readme", P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, first_order="readme", **kw)
+    assert_close(r.I_saved[0], ref1, RTOL, "README Lambertian first order")
+    ref = O.solve_column(col, literal=False)
+    assert r.n == ref.n
+    assert_close(r.I, ref.I, RTOL, "column on top of the README first order")
+    # more light comes back from a Lambertian ground than the coded first order (specular beam) accounts for at the top
+    coded = SOS_Aer("lambertian_readme", P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, **kw)
+    assert (r.I_saved[0] >= 0).all() and np.isfinite(r.I).all()
+    assert r.I_saved[0][0, N + 1:].sum() != coded.I_saved[0][0, N + 1:].sum()
+    # a black ground: both first orders are the direct-beam term alone
+    kw0 = dict(kw, grd_alb=0.0)
+    a = SOS_Aer("lambertian_readme", P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, first_order="readme", **kw0)
+    b = SOS_Aer("lambertian_readme", P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, **kw0)
+    assert_close(a.I_saved[0], b.I_saved[0], 1e-13, "rho = 0: README and coded first orders agree")
+    assert a.n == b.n

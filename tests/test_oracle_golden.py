@@ -173,3 +173,29 @@ def test_fp32_contraction_misses_the_parity_bar():
     res = S.study(L=40, N=32, ncol=2, out=io.StringIO())
     assert res["fp32/fp64"]["err"] > 1e-9 and res["fp32"]["err"] > 1e-8
     assert res["2xfp32"]["err"] < 1e-12 and res["2xfp32/f32"]["err"] > 1e-9
+
+
+def test_readme_lambertian_first_order_properties():
+    """PARITY UNPINNED (the reference has no runnable Lambertian first order).  The restatement of
+    README.md:126-171 reduces to the coded first order over a black ground, its ground terms are linear in the albedo,
+    and the removable singularity at mu' = mu is continuous (the limit agrees with the integrand next to it)."""
+    from sosrt import inputs
+    N, L, mu0 = 32, 40, 0.55
+    mu = inputs.direction_grid(N)
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, mu0)
+    P0r, Pr = inputs.phase_function("hg", N, mu, mu0, 0.7)
+
+    def fo(rho, readme=True):
+        c = O.make_column(mu0, 120, 25, 17, L, 0.124, 0.3, rho, 1.0, 0.9, N, P0a, Pa, P0r, Pr, surface="lambertian_readme")
+        return O.first_order_lambertian_readme(c) if readme else O.first_order(c)
+    base = fo(0.0)
+    np.testing.assert_array_equal(base, fo(0.0, readme=False))
+    a, b = fo(0.2) - base, fo(0.4) - base
+    assert np.isfinite(a).all() and (a >= 0).all() and a.max() > 0
+    # ground terms: the reflected-beam integral is linear in rho, the reflected downward first order adds a rho^2 part
+    # through the upward boundary only; the downward half is exactly linear
+    np.testing.assert_allclose(b[:, :N], 2 * a[:, :N], rtol=1e-12, atol=0)
+    assert (b[:, N + 1:] >= 2 * a[:, N + 1:] * (1 - 1e-12)).all()
+    # smooth across the quadrature node mu' = mu: the upward field has no spike on the grid
+    up = fo(0.3)[L // 2, N + 2:]
+    assert np.abs(np.diff(up, 2)).max() < 0.05 * up.max()
