@@ -114,9 +114,24 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     const int NCH = (L + TC - 1) / TC, NQ = 2 * NCH, R = NS - 1;
     const bool valid = tid < N;
     const int tidc = valid ? tid : N - 1;
-    auto touches = [&](int lo, int hi) {
-        return (zend0 >= lo && zend0 <= hi) || (zend1 >= lo && zend1 <= hi) || (zbeg1 >= lo && zbeg1 <= hi) ||
-               (zbeg2 >= lo && zbeg2 <= hi);
+    // Chunks with a zone boundary, and the last chunk of each sweep (its final row feeds the surface / the convergence test), go
+    // through the general body: one bit per chunk of a sweep.  More than 64 chunks per sweep: every chunk takes the general body.
+    unsigned long long sp_dn = NCH > 64 ? ~0ull : 1ull << (NCH - 1), sp_up = sp_dn;
+    if (NCH <= 64) {
+        const int zr[4] = {zend0, zend1, zbeg1, zbeg2};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (zr[i] >= 0) {
+                sp_dn |= 1ull << (zr[i] / TC);
+                sp_up |= 1ull << ((L - 1 - zr[i]) / TC);
+            }
+    }
+    // The plain chunks between two of those run in a loop of their own.  The general body in the same loop costs the plain
+    // chunks a third of their time although they never execute it (register copies where its values join the loop, spilled
+    // scalars reloaded in the hot path): a lone column 34 instead of 50 us without it (compiled out, in-kernel stamps).
+    auto plain_run = [&](unsigned long long mask, int j) {          // plain chunks from chunk j of the sweep on
+        const unsigned long long rest = NCH > 64 ? 1ull : mask >> j;
+        return rest ? __builtin_ctzll(rest) : 0;
     };
     double rdn_v = 0, rdn_i = 1, rup_v = 0, rup_i = 1;
     double sfc_own = 0;
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         if (wl) load_fix(0);
         const int sbase = small ? (m - g.small_lanes[0]) * L : 0;   // the small lanes are consecutive directions
         int t0 = 0, q = 0;
-        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) {
+        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) __attribute__((always_inline)) {
             constexpr bool SP = decltype(special_t)::value;
             double cc[TC], v[TC], Sc[TC];
 #pragma unroll
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             Jprev = Jc[TC - 1];
             t0 += TC;
         };
-        for (; q < NCH; ++q) {
+        auto chunk = [&](auto special_t) __attribute__((always_inline)) {
             const double* sp = ring + (size_t)slot_rd * SLOT + tid;
             slot_rd = slot_rd + 1 == NS ? 0 : slot_rd + 1;
             double Jc[TC], Ic[TC], Ec[TC];
@@ -351,10 +366,14 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 Ec[u] = sp[(1 * TC + u) * RS];
                 Ic[u] = ACC ? sp[(2 * TC + u) * RS] : 0.0;
             }
-            // general body: zone boundaries, and the last chunk (its final row feeds the surface and the test)
-            if (t0 + TC >= L || touches(t0, t0 + TC - 1)) process(std::true_type{}, sp - tid, Jc, Ic, Ec);
-            else process(std::false_type{}, sp - tid, Jc, Ic, Ec);
+            process(special_t, sp - tid, Jc, Ic, Ec);
             wg_barrier();
+        };
+        while (q < NCH) {
+            const int run = plain_run(sp_dn, q);
+            for (const int qe = q + run; q < qe; ++q) chunk(std::false_type{});
+            // general body: zone boundaries, and the last chunk (its final row feeds the surface and the test)
+            if (q < NCH) { chunk(std::true_type{}); ++q; }
         }
     }
 
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             return (tr && tid < kf) ? bl : x;
         };
         int t0 = L - 1, q = NCH;
-        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) {
+        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) __attribute__((always_inline)) {
             constexpr bool SP = decltype(special_t)::value;
             double cc[TC], v[TC];
 #pragma unroll
@@ -495,7 +514,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             Jnext = Jc[TC - 1];
             t0 -= TC;
         };
-        for (; q < NQ; ++q) {
+        auto chunk = [&](auto special_t) __attribute__((always_inline)) {
             const double* sp = ring + (size_t)slot_rd * SLOT + tid;
             slot_rd = slot_rd + 1 == NS ? 0 : slot_rd + 1;
             double Jc[TC], Ic[TC], Ec[TC];
@@ -505,10 +524,14 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 Ec[u] = sp[(1 * TC + u) * RS];
                 Ic[u] = ACC ? sp[(2 * TC + u) * RS] : 0.0;
             }
-            // general body: zone boundaries, and the last chunk (row 0 feeds the convergence test)
-            if (t0 - TC < 0 || touches(t0 - TC + 1, t0)) process(std::true_type{}, sp - tid, Jc, Ic, Ec);
-            else process(std::false_type{}, sp - tid, Jc, Ic, Ec);
+            process(special_t, sp - tid, Jc, Ic, Ec);
             wg_barrier();
+        };
+        while (q < NQ) {
+            const int run = plain_run(sp_up, q - NCH);
+            for (const int qe = q + run; q < qe; ++q) chunk(std::false_type{});
+            // general body: zone boundaries, and the last chunk (row 0 feeds the convergence test)
+            if (q < NQ) { chunk(std::true_type{}); ++q; }
         }
         if (w0 && notfound && lane == 0) s_flag[N - 3 <= 61 ? 1 : 0] = 1;
     }
