@@ -258,12 +258,17 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         if (wl) load_fix(0);
         const int sbase = small ? (m - g.small_lanes[0]) * L : 0;   // the small lanes are consecutive directions
         int t0 = 0, q = 0;
-        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) __attribute__((always_inline)) {
+        // MODE (plain chunks only; chosen once per run of plain chunks, which lies inside one zone): 0 this wave has no treated
+        // lane here, 1 the transposed extrapolation alone (the usual case of the wave with the mu -> 0- lanes), 2 anything else
+        // (|mu| < 0.01 lanes, more than 8 rewritten directions).  Modes 0 and 1 update no row conditionally: no register
+        // copies where the branches join.
+        auto process = [&](auto special_t, auto mode_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) __attribute__((always_inline)) {
             constexpr bool SP = decltype(special_t)::value;
+            constexpr int MODE = decltype(mode_t)::value;
             double cc[TC], v[TC], Sc[TC];
 #pragma unroll
             for (int u = 0; u < TC; ++u) Sc[u] = 0;
-            if (has_small) {
+            if ((SP || MODE == 2) && has_small) {
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
                     const double sv = s_S[sbase + min(t0 + u, L - 1)];
@@ -283,14 +288,14 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     Dv = rec_step(Dv, Ec[u], cc[u]);
                     v[u] = Dv;
                 }
-                if (has_small) {
+                if (MODE == 2 && has_small) {
 #pragma unroll
                     for (int u = 0; u < TC; ++u) v[u] = rec_add(v[u], Sc[u]);
                 }
                 // In_limit:113-141 as a linear map of the source lanes.  Up to 8 rewritten directions: the
                 // chunk goes through LDS and work item (uT, pT) does row uT, direction N-1-pT -- one pass for
                 // the 8 rows instead of 8 passes of cross-lane reads.
-                const bool tfix = wl && nfx > 0 && nfx <= 8 && sl[0] >= xb_dn;   // sources inside the 16-lane window
+                const bool tfix = MODE == 1 || (MODE == 2 && wl && nfx > 0 && nfx <= 8 && sl[0] >= xb_dn);   // sources inside the 16-lane window
                 if (tfix) {
 #pragma unroll
                     for (int u = 0; u < TC; ++u)
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                         if (ACC) bstore(rI, voT, 0, IcT + acc);
                         if (SAVED) bstore(rS, voT, 0, acc);
                     }
-                } else if (wl && nfx > 0) {
+                } else if (MODE == 2 && wl && nfx > 0) {
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         double acc = 0;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     }
                 }
             }
-            if (t0 + TC >= L) {
+            if (SP && t0 + TC >= L) {                           // (the last chunk of a sweep always takes the general body)
 #pragma unroll
                 for (int u = 0; u < TC; ++u)
                     if (t0 + u == L - 1) { sfc_own = v[u]; rdn_v = v[u]; rdn_i = Ic[u] + v[u]; }
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             Jprev = Jc[TC - 1];
             t0 += TC;
         };
-        auto chunk = [&](auto special_t) __attribute__((always_inline)) {
+        auto chunk = [&](auto special_t, auto mode_t) __attribute__((always_inline)) {
             const double* sp = ring + (size_t)slot_rd * SLOT + tid;
             slot_rd = slot_rd + 1 == NS ? 0 : slot_rd + 1;
             double Jc[TC], Ic[TC], Ec[TC];
@@ -366,14 +371,20 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 Ec[u] = sp[(1 * TC + u) * RS];
                 Ic[u] = ACC ? sp[(2 * TC + u) * RS] : 0.0;
             }
-            process(special_t, sp - tid, Jc, Ic, Ec);
+            process(special_t, mode_t, sp - tid, Jc, Ic, Ec);
             wg_barrier();
         };
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
         while (q < NCH) {
-            const int run = plain_run(sp_dn, q);
-            for (const int qe = q + run; q < qe; ++q) chunk(std::false_type{});
+            const int qe = q + plain_run(sp_dn, q);
+            const int mode = (!wl || (nfx == 0 && !has_small)) ? 0 : ((!has_small && nfx <= 8 && sl[0] >= xb_dn) ? 1 : 2);
+            if (mode == 0) for (; q < qe; ++q) chunk(std::false_type{}, M0{});
+            else if (mode == 1) for (; q < qe; ++q) chunk(std::false_type{}, M1{});
+            else for (; q < qe; ++q) chunk(std::false_type{}, M2{});
             // general body: zone boundaries, and the last chunk (its final row feeds the surface and the test)
-            if (q < NCH) { chunk(std::true_type{}); ++q; }
+            if (q < NCH) { chunk(std::true_type{}, M2{}); ++q; }
         }
     }
 
@@ -426,8 +437,10 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             return (tr && tid < kf) ? bl : x;
         };
         int t0 = L - 1, q = NCH;
-        auto process = [&](auto special_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) __attribute__((always_inline)) {
+        // MODE (plain chunks): 0 this wave has no mu -> 0+ lanes, 1 wave 0
+        auto process = [&](auto special_t, auto mode_t, const double* slot, double (&Jc)[TC], double (&Ic)[TC], double (&Ec)[TC]) __attribute__((always_inline)) {
             constexpr bool SP = decltype(special_t)::value;
+            constexpr int MODE = decltype(mode_t)::value;
             double cc[TC], v[TC];
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 // N+k of that row (blended below the stop, raw above it) -- one pass for the 8 rows.  A row whose
                 // search goes beyond 8 candidates sends the chunk through the row-by-row path.
                 bool tblend = false;
-                if (w0) {
+                if (MODE == 1) {
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         v[u] = tid == 0 ? Jc[u] : v[u];                  // spec:401
@@ -475,11 +488,20 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                             if (SAVED) bstore(rS, voT, 0, val);
                         }
                     } else {
+                        // (rare; stored here so that the rows are not updated conditionally: no copies at the join)
 #pragma unroll
-                        for (int u = 0; u < TC; ++u) v[u] = blend(v[u]);
+                        for (int u = 0; u < TC; ++u) {
+                            const double xb_ = blend(v[u]);
+                            if (valid) {
+                                const int so = (t0 - u) * RB;
+                                bstore(rIn, vo, so, xb_);
+                                if (ACC) bstore(rI, vo, so, Ic[u] + xb_);
+                                if (SAVED) bstore(rS, vo, so, xb_);
+                            }
+                        }
                     }
                 }
-                if (valid && !(tblend && tid >= 1 && tid <= 8)) {
+                if (valid && (MODE == 0 || (tblend && !(tid >= 1 && tid <= 8)))) {
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         const int so = (t0 - u) * RB;
@@ -506,7 +528,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     }
                 }
             }
-            if (t0 - TC < 0) {
+            if (SP && t0 - TC < 0) {
 #pragma unroll
                 for (int u = 0; u < TC; ++u)
                     if (t0 - u == 0) { rup_v = v[u]; rup_i = Ic[u] + v[u]; }
@@ -514,7 +536,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             Jnext = Jc[TC - 1];
             t0 -= TC;
         };
-        auto chunk = [&](auto special_t) __attribute__((always_inline)) {
+        auto chunk = [&](auto special_t, auto mode_t) __attribute__((always_inline)) {
             const double* sp = ring + (size_t)slot_rd * SLOT + tid;
             slot_rd = slot_rd + 1 == NS ? 0 : slot_rd + 1;
             double Jc[TC], Ic[TC], Ec[TC];
@@ -524,14 +546,17 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 Ec[u] = sp[(1 * TC + u) * RS];
                 Ic[u] = ACC ? sp[(2 * TC + u) * RS] : 0.0;
             }
-            process(special_t, sp - tid, Jc, Ic, Ec);
+            process(special_t, mode_t, sp - tid, Jc, Ic, Ec);
             wg_barrier();
         };
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
         while (q < NQ) {
-            const int run = plain_run(sp_up, q - NCH);
-            for (const int qe = q + run; q < qe; ++q) chunk(std::false_type{});
+            const int qe = q + plain_run(sp_up, q - NCH);
+            if (!w0) for (; q < qe; ++q) chunk(std::false_type{}, M0{});
+            else for (; q < qe; ++q) chunk(std::false_type{}, M1{});
             // general body: zone boundaries, and the last chunk (row 0 feeds the convergence test)
-            if (q < NQ) { chunk(std::true_type{}); ++q; }
+            if (q < NQ) { chunk(std::true_type{}, M1{}); ++q; }
         }
         if (w0 && notfound && lane == 0) s_flag[N - 3 <= 61 ? 1 : 0] = 1;
     }
