@@ -26,6 +26,8 @@ def _oracle(mu0, taer, rho, L, N, P_atm, P_aer, z_up, z_down, alb_aer, surface="
     (64, 48, (30, 10), [(0.7, 0.3, 0.2), (0.25, 1.0, 0.0)]),                     # 48 directions: one partly filled wave
     (50, 70, (40, 20), [(0.6, 0.2, 0.1), (0.9, 0.5, 0.2)]),                      # 70: extrapolation straddles two waves -> general kernel
     (90, 192, (25, 17), [(0.4, 0.12, 0.3)]),                                     # three waves per sweep
+    (600, 32, (25, 17), [(0.5, 0.12, 0.15)]),                                    # more than 64 chunks per sweep: every chunk takes the ring kernel's general body
+    (520, 64, (60, 30), [(0.6, 0.3, 0.2)]),                                      # 65 chunks, zone boundaries far down
 ])
 def test_shapes_match_oracle(L, N, zs, cols):
     mu = inputs.direction_grid(N)
