@@ -362,7 +362,6 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_GEMM_PAD_LDS")) h->coresident_pad = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUP_RING_SLOTS")) h->coresident_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
-    if (const char* ev = getenv("SOSRT_RING_LOADERS")) g_ring_loaders = atoi(ev);
 #ifdef SOSRT_RING_DEBUG   // diagnostic builds only: the switches make the ring kernel skip work, its results are wrong
     if (const char* ev = getenv("SOSRT_RING_DEBUG")) g_ring_debug = atoi(ev);
 #endif

@@ -1041,7 +1041,7 @@ static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm,
     if (mode == 1) {
         launch_transport_fast(s, grid, block, a);
     } else if (mode == 3) {
-        launch_transport_ring(s, grid, a, g_ring_slots, g_ring_loaders);
+        launch_transport_ring(s, grid, a, g_ring_slots);
     } else if (mode == 2) {
         if (a.accumulate) {
             if (a.saved) hipLaunchKernelGGL((k_transport<MAXT, true, true, true, true>), grid, block, shm, s, a);
@@ -1064,7 +1064,7 @@ static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm,
 }
 
 unsigned long long* g_transport_stamps = nullptr;
-int g_ring_slots = 3, g_ring_loaders = 2, g_ring_debug = 0;   // set by sosrt_debug_stamps (diagnostics)
+int g_ring_slots = 3, g_ring_debug = 0;   // set by sosrt_debug_stamps (diagnostics)
 
 // True when both mu -> 0 treatments of a column fit in wave 0 of k_transport_fast.
 bool transport_fast_ok(const Plan& plan) {

@@ -122,8 +122,8 @@ struct TransportArgs {
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
 bool transport_ring_ok(const Grid& g);
-void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots, int loaders);
-extern int g_ring_slots, g_ring_loaders, g_ring_debug;        // tuning (SOSRT_RING_SLOTS, SOSRT_RING_LOADERS)
+void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots);
+extern int g_ring_slots, g_ring_debug;                        // tuning (SOSRT_RING_SLOTS)
 extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
 
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,

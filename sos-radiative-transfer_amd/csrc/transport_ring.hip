@@ -690,14 +690,13 @@ bool transport_ring_ok(const Grid& g) {
     return 2 * slot_bytes + ring_extra_doubles(g, (nwc + 4) * 64) * sizeof(double) <= kRingLdsBytes;
 }
 
-// slots: ring depth wanted (2..6); loaders: loader waves per column
-void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots, int loaders) {
+// slots: ring depth wanted (2..6)
+void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots) {
     if (a.slots > 0) slots = a.slots;
     const int N = a.g.N;
     const int nwc = (N + 63) / 64;
     const int pieces = N <= 128 ? 1 : 2;
     const int narr = a.accumulate ? 3 : 2;
-    (void)loaders;                                                               // two loader waves (compile-time in the kernel)
     const dim3 block((nwc + 2) * 64);
     const size_t slot_bytes = (size_t)narr * TC * 128 * pieces * sizeof(double);
     const size_t extra = ring_extra_doubles(a.g, (int)block.x) * sizeof(double);
