@@ -163,6 +163,95 @@ __global__ __launch_bounds__(256) void k_skel(const double* A, const double* B, 
     if (tid == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
 
+// 7a. the skeleton with the rows of a chunk split between two sets of consumer waves (set P0 rows 0..TC/2-1, set P1 the
+//     rest), two barriers per chunk: in phase X the P0 waves run their part of the dependent chain (state handed over through
+//     LDS) and store, the P1 waves read their rows and prepare (WORK independent operations per row); in phase Y the roles
+//     swap.  What a column could cost with the recurrence as the only serial part.
+template <int TC, int NS, int WORK>
+__global__ __launch_bounds__(384) void k_skel_split(const double* A, const double* B, const double* C, double* O1, double* O2, int rows,
+                                                    long long* out) {
+    extern __shared__ double ring[];
+    constexpr int H = TC / 2, SLOT = 3 * TC * 128, R = NS - 2;
+    double* s_state = ring + (size_t)NS * SLOT;              // [128] recurrence state handed between the two sets
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int bytes = rows * 2048;
+    const size_t col = (size_t)blockIdx.x * rows * 256;
+    const __amdgpu_buffer_rsrc_t rA = rsrc(A + col, bytes), rB = rsrc(B + col, bytes), rC = rsrc(C + col, bytes);
+    const __amdgpu_buffer_rsrc_t r1 = rsrc(O1 + col, bytes), r2 = rsrc(O2 + col, bytes);
+    const int NCH = rows / TC;
+    if (tid < 128) s_state[tid] = 0;
+    const long long t0 = now();
+    if (wid >= 4) {                                          // loaders: one chunk per two barriers
+        const int lid = wid - 4;
+        int slot = 0;
+        auto issue = [&](int q) {
+            double* dst = ring + (size_t)slot * SLOT;
+            slot = slot + 1 == NS ? 0 : slot + 1;
+#pragma unroll
+            for (int i = 0; i < TC / 2; ++i) {
+                const int u = 2 * i + lid;
+                const int so = (q * TC + u) * 2048;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(dst + (0 * TC + u) * 128), 16, lane * 16, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(dst + (1 * TC + u) * 128), 16, lane * 16, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, (lds_ptr_t)(dst + (2 * TC + u) * 128), 16, lane * 16, so, 0, 0);
+            }
+        };
+        for (int q = 0; q < R + 1 && q < NCH; ++q) issue(q);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        constexpr int KEEP = R * (3 * TC / 2) > 60 ? 60 : R * (3 * TC / 2);
+        for (int q = 0; q < NCH; ++q) {
+            if (q + R + 1 < NCH) {
+                issue(q + R + 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+    } else {
+        const int p = wid >> 1, l = (wid & 1) * 64 + lane;   // row set, direction
+        double a[H], b[H], c[H], pre[H];
+        auto prepare = [&](int q) {                           // rows p*H .. p*H+H-1 of chunk q
+            const double* sp = ring + (size_t)(q % NS) * SLOT + l;
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                a[u] = sp[(0 * TC + p * H + u) * 128]; b[u] = sp[(1 * TC + p * H + u) * 128]; c[u] = sp[(2 * TC + p * H + u) * 128];
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                double y = a[u];
+#pragma unroll
+                for (int w = 0; w < WORK; ++w) y = __builtin_fma(y, b[u], a[u]);
+                pre[u] = y;
+            }
+        };
+        auto chain = [&](int q) {
+            double x = s_state[l];
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                x = __builtin_fma(x, b[u], pre[u]);
+                const int so = (q * TC + p * H + u) * 2048;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, x), r1, l * 8, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, c[u] + x), r2, l * 8, so, 0);
+            }
+            s_state[l] = x;
+        };
+        asm volatile("s_barrier" ::: "memory");
+        if (p == 0) prepare(0);
+        for (int q = 0; q < NCH; ++q) {
+            // phase X: P0 chain(q), P1 prepare(q)
+            if (p == 0) chain(q); else prepare(q);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // phase Y: P1 chain(q), P0 prepare(q + 1)
+            if (p == 1) chain(q); else if (q + 1 < NCH) prepare(q + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    const long long t1 = now();
+    if (tid == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+}
+
 // 7b. branch cost: a loop of n iterations with k uniform taken branches each (s_cbranch over one instruction)
 template <int K>
 __global__ void k_branch(int n, int z, long long* out, int* sink) {
@@ -348,6 +437,19 @@ int main() {
         SK(16, 3, 0, 1, 0, "TC 16, 3 slots, 1 fma, 8 B stores: all");
         SK(16, 3, 7, 1, 0, "TC 16, 3 slots, 1 fma: barriers only");
         SK(4, 3, 0, 1, 0, "TC 4, 3 slots, 1 fma, 8 B stores: all");
+        {
+            auto run_split = [&](auto kern, size_t shm, const char* what) {
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                for (int rep = 0; rep < 2; ++rep) { kern<<<1, 384, shm>>>(A, B, C, O1, O2, rows, d_out); CK(hipGetLastError()); CK(hipDeviceSynchronize()); }
+                const double t = get() * tick_ns;
+                printf("skeleton, rows of a chunk split between two wave sets, %-28s %.1f us (%.0f ns/chunk)\n", what, t / 1e3, t / (rows / 8));
+            };
+            run_split(k_skel_split<8, 4, 0>, (size_t)4 * 3 * 8 * 1024 + 1024, "0 operations per row:");
+            run_split(k_skel_split<8, 4, 3>, (size_t)4 * 3 * 8 * 1024 + 1024, "3 operations per row:");
+            run_split(k_skel_split<8, 4, 6>, (size_t)4 * 3 * 8 * 1024 + 1024, "6 operations per row:");
+            SK(8, 3, 0, 4, 0, "TC 8, 3 slots, 4 fma, 8 B stores: all");
+            SK(8, 3, 0, 7, 0, "TC 8, 3 slots, 7 fma, 8 B stores: all");
+        }
         run_skel(k_skel<8, 3, 0, 1, 0>, (size_t)3 * 3 * 8 * 1024, 64, "TC 8, 3 slots, 1 fma, 8 B stores: all", 8);
         run_skel(k_skel<8, 3, 0, 1, 0>, (size_t)3 * 3 * 8 * 1024, 256, "TC 8, 3 slots, 1 fma, 8 B stores: all", 8);
         run_skel(k_skel<8, 3, 0, 1, 0>, (size_t)3 * 3 * 8 * 1024, 512, "TC 8, 3 slots, 1 fma, 8 B stores: all", 8);
