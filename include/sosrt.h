@@ -95,10 +95,23 @@ int sosrt_set_first_order(sosrt_t* h, int mode);
  * SOSRT_CONTRACT_F32: operands rounded to float, v_mfma_f32_16x16x4_f32 with a float accumulator; transport, running
  * total and convergence test stay fp64.  About 3e-7 of the field maximum away from the fp64 result (measured on the
  * device: profiles/r02_mixed_precision_gpu.txt) -- an opt-in for callers with that tolerance, never the default.
- * Needs at most 32 distinct slab coefficient pairs in the batch. */
+ * Needs at most 32 distinct slab coefficient pairs in the batch.
+ *
+ * Within SOSRT_CONTRACT_F64 the library uses the flip symmetry of the folded matrices when they have it: every phase
+ * function of the scattering angle on a grid with mu[2N-1-k] = -mu[k] gives W[2N-1-k][2N-1-m] = W[k][m], and then
+ *   Jn[m] +- Jn[2N-1-m] = sum_{k<N} (In_1[k] +- In_1[2N-1-k]) (W[k][m] +- W[2N-1-k][m])
+ * -- two N x N products instead of one 2N x 2N, half the flops, same v_mfma_f64 arithmetic.  sosrt_set_phase measures
+ * max |W[k][m] - W[2N-1-k][2N-1-m]| / max |W| (sosrt_phase_asymmetry); at or below SOSRT_SYMMETRY_TOL (the rounding of
+ * the phase-matrix builders: 1e-14 for the reference's) the symmetric form is used on the symmetric part of W, so Jn moves
+ * by at most that fraction of max |W| sum |In_1| -- four orders of magnitude inside the 1e-10 parity bar; above it (any
+ * matrix without the symmetry) the full product runs.  SOSRT_CONTRACT_F64_FULL forces the full product. */
 #define SOSRT_CONTRACT_F64 0
 #define SOSRT_CONTRACT_F32 1
+#define SOSRT_CONTRACT_F64_FULL 2
+#define SOSRT_SYMMETRY_TOL 1e-12
 int sosrt_set_contraction(sosrt_t* h, int mode);
+/* asymmetry of the folded matrices of the last sosrt_set_phase (see above); *uses_symmetry: what the next solve will do */
+int sosrt_phase_asymmetry(sosrt_t* h, double* asymmetry, int* uses_symmetry);
 
 /* per-column scalars (the locals of spec:23-53).  Arrays have B entries.
  *   THREE_ZONE : idx_up, idx_down (spec:40), mu0, grd_alb, alb_atm, alb_aer, dtau_atm, dtau_aer

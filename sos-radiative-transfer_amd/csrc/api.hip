@@ -66,6 +66,8 @@ struct sosrt_handle {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ngroups = 1, want_groups = 1, split_min = 256;
+    int split_at = -1;                   // SOSRT_GROUP_SPLIT: first column of the second group (default: the middle)
+    int prio2 = 0;                       // SOSRT_GROUP_PRIO: the internal stream is created with the highest priority
     int coresident_pad = 27008;         // SOSRT_GEMM_PAD_LDS: 27 656 static + this > 1/3 of 160 KiB
     int coresident_slots = 2;           // SOSRT_GROUP_RING_SLOTS: ring depth of the transport when two groups share the CUs
     double stagger = 1.0;                // a group starts when the previous one is down to this fraction of live columns (SOSRT_STAGGER; 1: together)
@@ -109,6 +111,12 @@ struct sosrt_handle {
     int* d_mixgroup = nullptr;
     int* d_slabtilegroup = nullptr;      // [tiles] group of every 32-row slab tile of the dense contraction
     int contraction = SOSRT_CONTRACT_F64;
+    // flip-symmetric contraction (jn_gemm.hip, SYM): folded copies [k][S | A] of W_atm, W_aer and the combined matrices
+    double asymmetry = 0;                // max |W[k][m] - W[D-1-k][D-1-m]| / max |W| of the last sosrt_set_phase
+    bool sym_ok = false;                 // asymmetry <= SOSRT_SYMMETRY_TOL
+    bool sym_dirty = true, symmix_dirty = true;
+    double *d_Wa_s = nullptr, *d_Wr_s = nullptr, *d_Wmix_s = nullptr;
+    size_t mixs_capacity = 0;
     float *d_Wa32 = nullptr, *d_Wmix32 = nullptr;   // float copies of W_atm and of the combined slab matrices (SOSRT_CONTRACT_F32)
     size_t mix32_capacity = 0;
     bool w32_dirty = true;
@@ -263,6 +271,44 @@ int ensure_w32(sosrt_handle* h) {
     return 0;
 }
 
+bool use_sym(const sosrt_handle* h) { return h->contraction == SOSRT_CONTRACT_F64 && h->sym_ok; }
+
+// combined slab matrices and, for the symmetric contraction, the folded copies of every matrix (on stream s)
+int ensure_matrices(sosrt_handle* h, hipStream_t s) {
+    const Grid& g = h->g;
+    const size_t per = (size_t)g.Dp * g.Wld;
+    const bool mixed = h->mix_groups > 0 && h->mix_dirty;
+    if (mixed) {
+        prof_break(h);
+        launch_wmix(s, per, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
+        h->mix_dirty = false;
+        h->symmix_dirty = true;
+    }
+    if (!use_sym(h)) return 0;
+    if (h->sym_dirty) {
+        prof_break(h);
+        if (!h->d_Wa_s) { if (int e = dalloc(&h->d_Wa_s, per)) return e; }
+        if (!h->d_Wr_s) { if (int e = dalloc(&h->d_Wr_s, per)) return e; }
+        launch_symfold(s, 1, g.N, g.D, g.Dp, g.Wld, h->d_Wa, h->d_Wa_s);
+        launch_symfold(s, 1, g.N, g.D, g.Dp, g.Wld, h->d_Wr, h->d_Wr_s);
+        h->sym_dirty = false;
+    }
+    if (h->mix_groups > 0 && h->symmix_dirty) {
+        prof_break(h);
+        const size_t need = per * h->mix_groups;
+        if (need > h->mixs_capacity) {
+            // (the stream may still read the old buffer: hipFree synchronises)
+            if (h->d_Wmix_s) hipFree(h->d_Wmix_s);
+            h->d_Wmix_s = nullptr; h->mixs_capacity = 0;
+            if (int e = dalloc(&h->d_Wmix_s, need)) return e;
+            h->mixs_capacity = need;
+        }
+        launch_symfold(s, h->mix_groups, g.N, g.D, g.Dp, g.Wld, h->d_Wmix, h->d_Wmix_s);
+        h->symmix_dirty = false;
+    }
+    return 0;
+}
+
 // Jn for every row of a column group (grp < 0: the whole batch) in one launch: plain rows against W_atm, slab rows
 // against the combined matrix of their coefficient pair (or W_atm and W_aer in two passes)
 void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0,
@@ -294,13 +340,14 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
         ga.nactive = h->d_nactive + pg; ga.need_small = h->d_nactive + sosrt_handle::kMaxGroups;
         ga.host_pub = h->h_pub + 8 * pg; ga.tag = pub_tag;
     }
+    if (ensure_matrices(h, s)) return;                 // (allocation failure: reported by the caller's hipGetLastError / next call)
     if (h->mix_groups > 0) {
-        if (h->mix_dirty) {
-            prof_break(h);
-            launch_wmix(s, (size_t)h->g.Dp * h->g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
-            h->mix_dirty = false;
-        }
         ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; ga.slab_tile_group = h->d_slabtilegroup + h->slab_off[g0] / 32;
+    }
+    if (use_sym(h)) {
+        ga.sym = 1; ga.Ks = (h->g.N + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
+        ga.Wa = h->d_Wa_s; ga.Wr = h->d_Wr_s;
+        if (ga.Wmix) ga.Wmix = h->d_Wmix_s;
     }
     if (h->contraction == SOSRT_CONTRACT_F32) {
         // float operands, float accumulator: the dense tiling over the row lists for every order (tiles of converged
@@ -352,6 +399,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     h->saved_slots = max_orders;
     h->gpu = device >= 0;
     if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
+    if (const char* ev = getenv("SOSRT_CONTRACT"))            // "full": the D x D product whatever the symmetry of the matrices
+        if (strcmp(ev, "full") == 0) h->contraction = SOSRT_CONTRACT_F64_FULL;
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
         h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : 1);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
@@ -359,6 +408,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
     if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
     if (const char* ev = getenv("SOSRT_STAGGER")) h->stagger = atof(ev);
+    if (const char* ev = getenv("SOSRT_GROUP_SPLIT")) h->split_at = atoi(ev);
+    if (const char* ev = getenv("SOSRT_GROUP_PRIO")) h->prio2 = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_PAD_LDS")) h->coresident_pad = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUP_RING_SLOTS")) h->coresident_slots = atoi(ev);
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
@@ -375,7 +426,13 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             HIPCHK(hipSetDevice(device));
             HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
             h->stream = h->own_stream;
-            HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            if (h->prio2) {
+                int least = 0, greatest = 0;
+                HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, h->prio2 > 0 ? greatest : least));
+            } else {
+                HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            }
             HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             const size_t mb = max_batch, fe = field_elems(h);
@@ -452,7 +509,7 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr};
+                        h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -492,7 +549,7 @@ int sosrt_set_first_order(sosrt_t* h, int mode) {
 
 int sosrt_set_contraction(sosrt_t* h, int mode) {
     if (int e = need_gpu(h)) return e;
-    if (mode != SOSRT_CONTRACT_F64 && mode != SOSRT_CONTRACT_F32) return fail(SOSRT_E_INVALID, "unknown contraction mode %d", mode);
+    if (mode != SOSRT_CONTRACT_F64 && mode != SOSRT_CONTRACT_F32 && mode != SOSRT_CONTRACT_F64_FULL) return fail(SOSRT_E_INVALID, "unknown contraction mode %d", mode);
     if (mode == SOSRT_CONTRACT_F32) {
         HIPCHK(hipSetDevice(h->device));
         const size_t per = (size_t)h->g.Dp * h->g.Wld;
@@ -500,6 +557,14 @@ int sosrt_set_contraction(sosrt_t* h, int mode) {
         h->w32_dirty = true;
     }
     h->contraction = mode;
+    return 0;
+}
+
+int sosrt_phase_asymmetry(sosrt_t* h, double* asymmetry, int* uses_symmetry) {
+    if (!h) return fail(SOSRT_E_INVALID, "null handle");
+    if (!h->have_phase) return fail(SOSRT_E_STATE, "sosrt_set_phase has not been called");
+    if (asymmetry) *asymmetry = h->asymmetry;
+    if (uses_symmetry) *uses_symmetry = use_sym(h) ? 1 : 0;
     return 0;
 }
 
@@ -566,6 +631,27 @@ int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer) {
     h->have_phase = true;
     h->mix_dirty = true;
     h->w32_dirty = true;
+    h->sym_dirty = true; h->symmix_dirty = true;
+    {   // flip symmetry of the folded matrices (see sosrt.h, sosrt_set_contraction)
+        const int D = h->D;
+        h->asymmetry = 0;
+        for (const std::vector<double>* W : {&h->Wa_h, &h->Wr_h}) {
+            if (W->empty()) continue;
+            double wmax = 0, amax = 0;
+            for (int k = 0; k < D; ++k)
+                for (int m = 0; m < D; ++m) {
+                    const double x = (*W)[(size_t)k * D + m], y = (*W)[(size_t)(D - 1 - k) * D + (D - 1 - m)];
+                    const double ax = std::fabs(x), d = std::fabs(x - y);
+                    if (!(ax <= wmax)) wmax = ax;          // a NaN ends up here and switches the symmetric form off
+                    if (!(d <= amax)) amax = d;
+                }
+            const double r = wmax > 0 ? amax / wmax : 0.0;
+            if (!(r <= h->asymmetry)) h->asymmetry = r;
+        }
+        double tol = SOSRT_SYMMETRY_TOL;
+        if (const char* ev = getenv("SOSRT_SYMMETRY_TOL")) tol = atof(ev);
+        h->sym_ok = h->asymmetry <= tol;
+    }
     if (h->gpu) {
         HIPCHK(hipSetDevice(h->device));
         const Grid& g = h->g;
@@ -590,7 +676,7 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
     auto zone_end = [&](int b, int z) { return z + 1 < nz[b] ? zr0[b * kMaxZones + z + 1] - 1 : L - 1; };
     // column groups of the order loop: two contiguous halves for a large batch
     h->ngroups = (h->want_groups >= 2 && B >= h->split_min && B >= 2) ? 2 : 1;
-    h->gb[0] = 0; h->gb[1] = h->ngroups == 2 ? B / 2 : B; h->gb[2] = B;
+    h->gb[0] = 0; h->gb[1] = h->ngroups == 2 ? ((h->split_at > 0 && h->split_at < B) ? h->split_at : B / 2) : B; h->gb[2] = B;
     for (int k = 0; k <= sosrt_handle::kMaxGroups; ++k) { h->main_off[k] = 0; h->slab_off[k] = 0; }
     h->max_nz = 1;
     h->simple_zones = true;                  // every column is (clear, slab, clear): the live-column tilings apply
@@ -911,10 +997,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         small_published = true;
     }
     if (fast) HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), s));
-    if (h->mix_groups > 0 && h->mix_dirty) {
-        launch_wmix(s, (size_t)g.Dp * g.Wld, h->mix_groups, h->d_Wa, h->d_Wr, h->d_mixca, h->d_mixcr, h->d_Wmix);
-        h->mix_dirty = false;
-    }
+    if (int e = ensure_matrices(h, s)) return e;
     if (NG > 1) {                                    // the second column group runs on the internal stream from here on
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
@@ -1000,7 +1083,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             const size_t fo = (size_t)q.b0 * LD;
             // this launch also publishes the group's live count after order n-1
             // (the float contraction has the dense tiling only: no live list for the transport either)
-            const int tail_cols = (h->contraction == SOSRT_CONTRACT_F64 && h->simple_zones && q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
+            const int tail_cols = (h->contraction != SOSRT_CONTRACT_F32 && h->simple_zones && q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
             run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway

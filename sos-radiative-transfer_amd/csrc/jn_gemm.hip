@@ -46,10 +46,19 @@ struct ColumnRows {             // the plain or the slab rows of one column
 
 // wmix (slab tiles of one column only): the column's combined matrix ca W_atm + cr W_aer -- one pass over k
 // with unit coefficients instead of two passes
-template <int RT, bool SLAB, bool DEEP = false, class RowOf = ListRows>
+//
+// SYM (flip-symmetric matrices, W[D-1-k][D-1-m] = W[k][m] -- every phase function of the scattering angle on a
+// symmetric direction grid): with a_k = In_1[k], b_k = In_1[D-1-k], u = a + b, v = a - b (k < N),
+//     Jn[m] = X + Y,  Jn[D-1-m] = X - Y,   X = sum_k u_k S[k][m],  Y = sum_k v_k A[k][m]   (m < N)
+// S = (W[k][m] + W[D-1-k][m]) / 2, A = (W[k][m] - W[D-1-k][m]) / 2 (k_symfold): two N x N products instead of one
+// D x D -- half the flops.  The workgroup's 128 columns are 64 values of m, X and Y each; a wave keeps X in its
+// first column tile and Y in its second.  The matrices are stored [k][S: 0..Wld/2 | A: Wld/2..Wld].
+template <int RT, bool SLAB, bool DEEP = false, bool SYM = false, class RowOf = ListRows>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile, int bn0,
                                           RowOf row_of, bool check_active, const double* __restrict__ wmix = nullptr) {
     constexpr int BM = 16 * RT;
+    double* const sAv = sA + BM * A_LD;          // SYM: the v operand next to the u operand
+    const int Nn = g.D >> 1, Nh = g.Wld >> 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int D = g.D, Dp = g.Dp, Wld = g.Wld;
@@ -81,16 +90,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     constexpr int AQ = GEMM_KC / 8;                       // double2 per thread of an A chunk
     const int bk = tid / (GEMM_BN / (2 * BQ)), bc = (tid % (GEMM_BN / (2 * BQ))) * 2 * BQ;
     const int fr = lane & 15, fk = lane >> 4;
-    const int nck = Dp / GEMM_KC;                 // chunks per pass
+    const int nck = (SYM ? g.Ks : Dp) / GEMM_KC;  // chunks per pass
     const int ntot = slab ? 2 * nck : nck;
+    // SYM: this thread's 8 doubles of a W chunk are 8 columns of S (first half of the staging row) or of A
+    const int bcol = SYM ? (bc < GEMM_BN / 2 ? (bn0 >> 1) + bc : Nh + (bn0 >> 1) + bc - GEMM_BN / 2) : bn0 + bc;
 
     // Register staging as plain named values (arrays passed through lambdas end up in scratch).  The A
     // operand (In_1, from HBM) is staged two chunks ahead, the W operand (L2-resident) one chunk ahead.
     struct StageA { double2 a[AQ]; };
+    struct StageM { double2 m[AQ]; };                   // the mirrored elements (In_1[D-1-k]; SYM only, else never touched)
     StageA s0;
+    StageM m0;
     double2 sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;     // named: an array here ends up in scratch
     // global -> registers for chunk c (clamped: every call issues the same loads)
-#define SOSRT_GLOAD_A(ST, c_)                                                                             \
+#define SOSRT_GLOAD_A(ST, SM, c_)                                                                            \
     {                                                                                                     \
         const int cc_ = min((c_), ntot - 1);                                                              \
         const int kc_ = (cc_ >= nck ? cc_ - nck : cc_) * GEMM_KC;                                         \
@@ -98,6 +111,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
             const int k0_ = kc_ + akq + 2 * q;                                                            \
             ST.a[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + k0_)          \
                                                  : make_double2(0, 0);                                    \
+            if (SYM) SM.m[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + D - 2 - k0_) \
+                                                          : make_double2(0, 0);                           \
         }                                                                                                 \
     }
 #define SOSRT_GLOAD_B(c_)                                                                                 \
@@ -106,21 +121,35 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
         const int pass_ = cc_ >= nck ? 1 : 0;                                                             \
         const int kc_ = (cc_ - pass_ * nck) * GEMM_KC;                                                    \
         const double* __restrict__ W_ = wmix ? wmix : (pass_ ? g.Wr : g.Wa);                                              \
-        const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bn0 + bc;                                     \
+        const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bcol;                                         \
         sb0 = *reinterpret_cast<const double2*>(Wp_); sb1 = *reinterpret_cast<const double2*>(Wp_ + 2);    \
         sb2 = *reinterpret_cast<const double2*>(Wp_ + 4); sb3 = *reinterpret_cast<const double2*>(Wp_ + 6); \
         if (BQ > 4) {                                                                                     \
         sb4 = *reinterpret_cast<const double2*>(Wp_ + 8); sb5 = *reinterpret_cast<const double2*>(Wp_ + 10); \
         sb6 = *reinterpret_cast<const double2*>(Wp_ + 12); sb7 = *reinterpret_cast<const double2*>(Wp_ + 14); } \
     }
-#define SOSRT_LSTORE(ST, c_)                                                                              \
+#define SOSRT_ASTORE(ST, SM, c_)                                                                          \
     {                                                                                                     \
         const double cf_ = (c_) >= nck ? coef_r : coef_a;                                                 \
         if (arow < BM) {                       /* fewer rows than staging threads in the small tiles */      \
-        _Pragma("unroll") for (int q = 0; q < AQ; ++q)                                                    \
-            *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                                 \
-                make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                           \
+        _Pragma("unroll") for (int q = 0; q < AQ; ++q) {                                                  \
+            if (SYM) {                                                                                    \
+                const int k0_ = ((c_) >= nck ? (c_) - nck : (c_)) * GEMM_KC + akq + 2 * q;                \
+                const bool v0_ = k0_ < Nn, v1_ = k0_ + 1 < Nn;                                            \
+                *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                             \
+                    make_double2(v0_ ? cf_ * (ST.a[q].x + SM.m[q].y) : 0.0, v1_ ? cf_ * (ST.a[q].y + SM.m[q].x) : 0.0); \
+                *reinterpret_cast<double2*>(&sAv[arow * A_LD + akq + 2 * q]) =                            \
+                    make_double2(v0_ ? cf_ * (ST.a[q].x - SM.m[q].y) : 0.0, v1_ ? cf_ * (ST.a[q].y - SM.m[q].x) : 0.0); \
+            } else {                                                                                      \
+                *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                             \
+                    make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                       \
+            }                                                                                             \
         }                                                                                                 \
+        }                                                                                                 \
+    }
+#define SOSRT_LSTORE(ST, SM, c_)                                                                          \
+    {                                                                                                     \
+        SOSRT_ASTORE(ST, SM, c_)                                                                            \
         double2* sbp_ = reinterpret_cast<double2*>(&sB[bk * B_LD + bc]);                                  \
         sbp_[0] = sb0; sbp_[1] = sb1; sbp_[2] = sb2; sbp_[3] = sb3;                                       \
         if (BQ > 4) { sbp_[4] = sb4; sbp_[5] = sb5; sbp_[6] = sb6; sbp_[7] = sb7; }                       \
@@ -131,6 +160,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
             double af[RT], bf[2];
 #pragma unroll
             for (int i = 0; i < RT; ++i) af[i] = sA[(i * 16 + fr) * A_LD + kk + fk];
+            if (SYM) {
+                double av[RT];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) av[i] = sAv[(i * 16 + fr) * A_LD + kk + fk];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = sB[(kk + fk) * B_LD + j * (GEMM_BN / 2) + wave * 16 + fr];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bf[1], acc[i][1], 0, 0, 0);
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = sB[(kk + fk) * B_LD + wave * 32 + j * 16 + fr];
 #pragma unroll
@@ -142,13 +184,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     };
 
     if (!DEEP) {
-        SOSRT_GLOAD_A(s0, 0);
+        SOSRT_GLOAD_A(s0, m0, 0);
         SOSRT_GLOAD_B(0);
         for (int c = 0; c < ntot; ++c) {
             __syncthreads();                 // previous chunk consumed
-            SOSRT_LSTORE(s0, c);
+            SOSRT_LSTORE(s0, m0, c);
             __syncthreads();
-            SOSRT_GLOAD_A(s0, c + 1);
+            SOSRT_GLOAD_A(s0, m0, c + 1);
             SOSRT_GLOAD_B(c + 1);
             compute();
         }
@@ -158,7 +200,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
         // two so that a set in flight is never copied.
         struct Stage { double2 a[AQ]; double2 b[BQ]; };
         Stage t0, t1;
-#define SOSRT_GLOAD2(ST, c_)                                                                              \
+        StageM m1;
+#define SOSRT_GLOAD2(ST, SM, c_)                                                                          \
     {                                                                                                     \
         const int cc_ = min((c_), ntot - 1);                                                              \
         const int pass_ = cc_ >= nck ? 1 : 0;                                                             \
@@ -167,35 +210,32 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
             const int k0_ = kc_ + akq + 2 * q;                                                            \
             ST.a[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + k0_)          \
                                                  : make_double2(0, 0);                                    \
+            if (SYM) SM.m[q] = (grow >= 0 && k0_ + 1 < D) ? *reinterpret_cast<const double2*>(Arow + D - 2 - k0_) \
+                                                          : make_double2(0, 0);                           \
         }                                                                                                 \
         const double* __restrict__ W_ = wmix ? wmix : (pass_ ? g.Wr : g.Wa);                                              \
-        const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bn0 + bc;                                     \
+        const double* Wp_ = W_ + (size_t)(kc_ + bk) * Wld + bcol;                                         \
         _Pragma("unroll") for (int q = 0; q < BQ; ++q) ST.b[q] = *reinterpret_cast<const double2*>(Wp_ + 2 * q); \
     }
-#define SOSRT_LSTORE2(ST, c_)                                                                             \
+#define SOSRT_LSTORE2(ST, SM, c_)                                                                          \
     {                                                                                                     \
-        const double cf_ = (c_) >= nck ? coef_r : coef_a;                                                 \
-        if (arow < BM) {                       /* fewer rows than staging threads in the small tiles */      \
-        _Pragma("unroll") for (int q = 0; q < AQ; ++q)                                                    \
-            *reinterpret_cast<double2*>(&sA[arow * A_LD + akq + 2 * q]) =                                 \
-                make_double2(cf_ * ST.a[q].x, cf_ * ST.a[q].y);                                           \
-        }                                                                                                 \
+        SOSRT_ASTORE(ST, SM, c_)                                                                            \
         double2* sbp_ = reinterpret_cast<double2*>(&sB[bk * B_LD + bc]);                                  \
         _Pragma("unroll") for (int q = 0; q < BQ; ++q) sbp_[q] = ST.b[q];                                 \
     }
-        SOSRT_GLOAD2(t0, 0);
-        SOSRT_GLOAD2(t1, 1);
+        SOSRT_GLOAD2(t0, m0, 0);
+        SOSRT_GLOAD2(t1, m1, 1);
         for (int c = 0; c < ntot; c += 2) {
             __syncthreads();
-            SOSRT_LSTORE2(t0, c);
+            SOSRT_LSTORE2(t0, m0, c);
             __syncthreads();
-            SOSRT_GLOAD2(t0, c + 2);
+            SOSRT_GLOAD2(t0, m0, c + 2);
             compute();
             if (c + 1 < ntot) {
                 __syncthreads();
-                SOSRT_LSTORE2(t1, c + 1);
+                SOSRT_LSTORE2(t1, m1, c + 1);
                 __syncthreads();
-                SOSRT_GLOAD2(t1, c + 3);
+                SOSRT_GLOAD2(t1, m1, c + 3);
                 compute();
             }
         }
@@ -205,13 +245,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
 #undef SOSRT_GLOAD_A
 #undef SOSRT_GLOAD_B
 #undef SOSRT_LSTORE
+#undef SOSRT_ASTORE
     // epilogue: lane holds column (l & 15), rows 4r + (l >> 4)
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gr = row_of(bm0 + i * 16 + 4 * r + fk);
-            if (gr >= 0) {
+            if (SYM) {
+                const int m = (bn0 >> 1) + wave * 16 + fr;
+                if (gr >= 0 && m < Nn) {
+                    const double x = acc[i][0][r], y = acc[i][1][r];
+                    g.C[(size_t)gr * D + m] = x + y;
+                    g.C[(size_t)gr * D + D - 1 - m] = x - y;
+                }
+            } else if (gr >= 0) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = bn0 + wave * 32 + j * 16 + fr;
@@ -222,9 +270,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     }
 }
 
+template <bool SYM>
 __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     publish_live(g);
-    __shared__ double sA[16 * (GEMM_RT > 2 ? GEMM_RT : 2) * A_LD];
+    __shared__ double sA[(SYM ? 2 : 1) * 16 * (GEMM_RT > 2 ? GEMM_RT : 2) * A_LD];
     __shared__ double sB[GEMM_KC * B_LD];
     __shared__ int s_any;
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  The column tiles of one row
@@ -237,16 +286,16 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     const int tile = (id / (8 * nct)) * 8 + (id & 7), bn0 = ((id >> 3) % nct) * GEMM_BN;
     if (tile >= tiles) return;
     if (tile < tiles_main) {
-        gemm_tile<GEMM_RT, false>(g, sA, sB, &s_any, tile, bn0, ListRows{g.rows_main, g.n_main}, true);
+        gemm_tile<GEMM_RT, false, false, SYM>(g, sA, sB, &s_any, tile, bn0, ListRows{g.rows_main, g.n_main}, true);
     } else if (g.Wmix && g.slab_tile_group) {
         // the slab rows are listed group by group (one distinct coefficient pair per 32-row tile): one pass over the
         // group's combined matrix, the same arithmetic as the live-column tilings (a column's result does not
         // depend on which tiling, or which batch, it was computed in)
         const int st = tile - tiles_main;
-        gemm_tile<2, false>(g, sA, sB, &s_any, st, bn0, ListRows{g.rows_slab, g.n_slab}, true,
-                            g.Wmix + (size_t)g.slab_tile_group[st] * g.Dp * g.Wld);
+        gemm_tile<2, false, false, SYM>(g, sA, sB, &s_any, st, bn0, ListRows{g.rows_slab, g.n_slab}, true,
+                                        g.Wmix + (size_t)g.slab_tile_group[st] * g.Dp * g.Wld);
     } else {
-        gemm_tile<2, true>(g, sA, sB, &s_any, tile - tiles_main, bn0, ListRows{g.rows_slab, g.n_slab}, true);
+        gemm_tile<2, true, false, SYM>(g, sA, sB, &s_any, tile - tiles_main, bn0, ListRows{g.rows_slab, g.n_slab}, true);
     }
 }
 
@@ -257,7 +306,7 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
 // column's rows: 16-row tiles for the slab rows, scheduled first because their double pass over k is
 // the critical path of the launch, then the tiles of the plain rows.
 constexpr int TAIL_RT_SLAB = 1;
-template <int RT, bool DEEP>
+template <int RT, bool DEEP, bool SYM>
 __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA, double* sB) {
     __shared__ int s_w[4];
     __shared__ int s_col;
@@ -295,32 +344,34 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     if (tt < ts) {
         if (tt * 16 * TAIL_RT_SLAB >= ns) return;
         if (g.Wmix)      // SLAB = false: a single pass, over the column's combined matrix
-            gemm_tile<TAIL_RT_SLAB, false, DEEP>(g, sA, sB, nullptr, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true},
-                                                 false, g.Wmix + (size_t)g.mix_group[b] * g.Dp * g.Wld);
+            gemm_tile<TAIL_RT_SLAB, false, DEEP, SYM>(g, sA, sB, nullptr, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true},
+                                                      false, g.Wmix + (size_t)g.mix_group[b] * g.Dp * g.Wld);
         else
-            gemm_tile<TAIL_RT_SLAB, true, DEEP>(g, sA, sB, nullptr, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true}, false);
+            gemm_tile<TAIL_RT_SLAB, true, DEEP, SYM>(g, sA, sB, nullptr, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true}, false);
     } else {
         const int t2 = tt - ts;
         if (t2 * 16 * RT >= g.L - ns) return;
-        gemm_tile<RT, false, DEEP>(g, sA, sB, nullptr, t2, bn0, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
+        gemm_tile<RT, false, DEEP, SYM>(g, sA, sB, nullptr, t2, bn0, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, false);
     }
 }
 
 // many live columns: the tile of the dense kernel
+template <bool SYM>
 __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm_cols(GemmArgs g) {
     publish_live(g);
-    __shared__ double sA[16 * GEMM_RT * A_LD];
+    __shared__ double sA[(SYM ? 2 : 1) * 16 * GEMM_RT * A_LD];
     __shared__ double sB[GEMM_KC * B_LD];
-    gemm_live_columns<GEMM_RT, false>(g, sA, sB);
+    gemm_live_columns<GEMM_RT, false, SYM>(g, sA, sB);
 }
 // few live columns: 32-row tiles (more workgroups, so more CUs take part) and deeper staging, since
 // such a workgroup is alone on its CU
 constexpr int TAIL_RT = 2;
+template <bool SYM>
 __global__ __launch_bounds__(256, 2) void k_jn_gemm_tail(GemmArgs g) {
     publish_live(g);
-    __shared__ double sA[16 * TAIL_RT * A_LD];
+    __shared__ double sA[(SYM ? 2 : 1) * 16 * TAIL_RT * A_LD];
     __shared__ double sB[GEMM_KC * B_LD];
-    gemm_live_columns<TAIL_RT, true>(g, sA, sB);
+    gemm_live_columns<TAIL_RT, true, SYM>(g, sA, sB);
 }
 
 }  // namespace
@@ -332,8 +383,13 @@ void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_til
     if (cols <= 0 || ts + tm <= 0) return;
     const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
     dim3 grid((unsigned)((cols * (ts + tm) + 7) / 8 * 8 * nct));
-    if (small_tiles) hipLaunchKernelGGL(k_jn_gemm_tail, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_jn_gemm_cols, grid, dim3(256), (size_t)a.pad_lds, s, a);
+    if (small_tiles) {
+        if (a.sym) hipLaunchKernelGGL(k_jn_gemm_tail<true>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_jn_gemm_tail<false>, grid, dim3(256), 0, s, a);
+    } else {
+        if (a.sym) hipLaunchKernelGGL(k_jn_gemm_cols<true>, grid, dim3(256), (size_t)a.pad_lds, s, a);
+        else hipLaunchKernelGGL(k_jn_gemm_cols<false>, grid, dim3(256), (size_t)a.pad_lds, s, a);
+    }
 }
 
 // Wmix[g] = ca[g] W_atm + cr[g] W_aer for every distinct slab coefficient pair of the batch
@@ -354,7 +410,33 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     if (tiles <= 0) return;
     const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
     dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nct));
-    hipLaunchKernelGGL(k_jn_gemm, grid, dim3(256), (size_t)a.pad_lds, s, a);
+    if (a.sym) hipLaunchKernelGGL(k_jn_gemm<true>, grid, dim3(256), (size_t)a.pad_lds, s, a);
+    else hipLaunchKernelGGL(k_jn_gemm<false>, grid, dim3(256), (size_t)a.pad_lds, s, a);
+}
+
+// Flip-symmetric folding of a contraction matrix (gemm_tile, SYM): for k, m < N, with k' = D-1-k, m' = D-1-m,
+//     S[k][m] = (W[k][m] + W[k'][m'] + W[k'][m] + W[k][m']) / 4,   A[k][m] = (W[k][m] + W[k'][m'] - W[k'][m] - W[k][m']) / 4
+// (the symmetric part of W; what is dropped is W[k][m] - W[k'][m'], the rounding of the phase-matrix builders, which the
+// host has checked to be negligible).  Stored [k][S: 0..Wld/2 | A: Wld/2..Wld], zero elsewhere.
+__global__ void k_symfold(int nmat, int N, int D, int Dp, int Wld, const double* __restrict__ W, double* __restrict__ SA) {
+    const size_t per = (size_t)Dp * Wld;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * nmat) return;
+    const size_t mat = i / per, r = i % per;
+    const int k = (int)(r / Wld), c = (int)(r % Wld), Nh = Wld >> 1;
+    const int m = c < Nh ? c : c - Nh;
+    double out = 0.0;
+    if (k < N && m < N) {
+        const double* w = W + mat * per;
+        const double p = w[(size_t)k * Wld + m], pf = w[(size_t)(D - 1 - k) * Wld + (D - 1 - m)];
+        const double q = w[(size_t)(D - 1 - k) * Wld + m], qf = w[(size_t)k * Wld + (D - 1 - m)];
+        out = c < Nh ? 0.25 * ((p + pf) + (q + qf)) : 0.25 * ((p + pf) - (q + qf));
+    }
+    SA[i] = out;
+}
+void launch_symfold(hipStream_t s, int nmat, int N, int D, int Dp, int Wld, const double* W, double* SA) {
+    const size_t n = (size_t)Dp * Wld * nmat;
+    hipLaunchKernelGGL(k_symfold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nmat, N, D, Dp, Wld, W, SA);
 }
 
 }  // namespace sosrt

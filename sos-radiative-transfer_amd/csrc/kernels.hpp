@@ -170,6 +170,9 @@ struct GemmArgs {
     const int* need_small = nullptr; // [1]: whether any column of the batch needs k_smallmu (set by k_prepare)
     int* host_pub = nullptr;         // pinned [2 slots][4] = {live, tag, needs k_smallmu, -}; slot = tag & 1
     int tag = 0;
+    // flip-symmetric contraction (jn_gemm.hip, SYM): Wa / Wr / Wmix then hold the folded matrices [k < Ks][S | A]
+    int sym = 0;
+    int Ks = 0;                      // N rounded up to the k-chunk
 };
 
 __device__ inline void publish_live(const GemmArgs& g) {
@@ -187,6 +190,8 @@ void launch_gemm_f32(hipStream_t s, const GemmArgs& a, const float* Wa32, const 
 void launch_to_float(hipStream_t s, size_t n, const double* src, float* dst);
 void launch_wmix(hipStream_t s, size_t n, int ngroups, const double* Wa, const double* Wr, const double* ca, const double* cr,
                  double* Wmix);
+// the flip-symmetric folding [k][S | A] of `nmat` contraction matrices [Dp][Wld]
+void launch_symfold(hipStream_t s, int nmat, int N, int D, int Dp, int Wld, const double* W, double* SA);
 // some columns have converged (at most `cols` are live, an upper bound): workgroups only for live
 // columns; small_tiles: 32-row tiles and deeper staging for the last few
 void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles);

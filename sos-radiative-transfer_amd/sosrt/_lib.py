@@ -15,7 +15,7 @@ COL_OK, COL_INDEXERROR, COL_MAXORDERS = 0, 1, 2
 GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
 SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN, SURFACE_LAMBERTIAN_README = 0, 1, 2, 3
 K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU = 0, 1, 2, 3
-CONTRACT_F64, CONTRACT_F32 = 0, 1
+CONTRACT_F64, CONTRACT_F32, CONTRACT_F64_FULL = 0, 1, 2
 FIRST_ORDER_CODED, FIRST_ORDER_README = 0, 1
 PHASE_ISO, PHASE_RAYLEIGH, PHASE_HG, PHASE_TABLE = 0, 1, 2, 3
 
@@ -32,6 +32,7 @@ SIGNATURES = {
     "sosrt_synchronize": (c_int, [c_void_p]),
     "sosrt_set_saved_orders": (c_int, [c_void_p, c_int]),
     "sosrt_set_contraction": (c_int, [c_void_p, c_int]),
+    "sosrt_phase_asymmetry": (c_int, [c_void_p, POINTER(c_double), _ip]),
     "sosrt_set_first_order": (c_int, [c_void_p, c_int]),
     "sosrt_set_grid": (c_int, [c_void_p, c_void_p]),
     "sosrt_set_phase": (c_int, [c_void_p, c_void_p, c_void_p]),

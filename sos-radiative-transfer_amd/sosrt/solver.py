@@ -75,12 +75,19 @@ class Solver:
         check(lib().sosrt_synchronize(self._h))
 
     def set_contraction(self, mode="f64"):
-        """'f64' (default, the parity path) | 'f32' (float operands and accumulator in the Jn contraction: opt-in,
-        about 3e-7 away from the fp64 result; BASELINE configs[4])."""
-        m = {"f64": _lib.CONTRACT_F64, "f32": _lib.CONTRACT_F32}.get(mode)
+        """'f64' (default, the parity path: fp64 MFMA, using the flip symmetry of the folded matrices when they have it) |
+        'f64_full' (fp64 MFMA, always the full 2N x 2N product) | 'f32' (float operands and accumulator in the Jn
+        contraction: opt-in, about 3e-7 away from the fp64 result; BASELINE configs[4])."""
+        m = {"f64": _lib.CONTRACT_F64, "f32": _lib.CONTRACT_F32, "f64_full": _lib.CONTRACT_F64_FULL}.get(mode)
         if m is None:
-            raise ValueError("contraction must be 'f64' or 'f32'")
+            raise ValueError("contraction must be 'f64', 'f64_full' or 'f32'")
         check(lib().sosrt_set_contraction(self._h, m))
+
+    def phase_asymmetry(self):
+        """(max |W[k][m] - W[2N-1-k][2N-1-m]| / max |W| of the folded matrices, whether the next solve uses the symmetry)"""
+        a, u = ctypes.c_double(), ctypes.c_int()
+        check(lib().sosrt_phase_asymmetry(self._h, ctypes.byref(a), ctypes.byref(u)))
+        return a.value, bool(u.value)
 
     def set_first_order(self, mode="coded"):
         """'coded' (default): spec:104-292, what both mains of the reference compute (specularly reflected beam).
