@@ -189,6 +189,37 @@ def transport_model(Jn, tau, mu, N, zones, nfix, surface, rho):
     return In, status
 
 
-def source_model(In_1, Wa, Wr, ca, cr):
-    """ca, cr: per-row coefficients."""
+def source_model(In_1, Wa, Wr, ca, cr, symmetric=False):
+    """ca, cr: per-row coefficients.  symmetric: the flip-symmetric form of the kernels (jn_gemm.hip, SYM)."""
+    if symmetric:
+        return ca[:, None] * source_symmetric(In_1, Wa) + cr[:, None] * source_symmetric(In_1, Wr)
     return ca[:, None] * (In_1 @ Wa) + cr[:, None] * (In_1 @ Wr)
+
+
+def asymmetry(W):
+    """max |W[k, m] - W[D-1-k, D-1-m]| / max |W|: what sosrt_set_phase measures (0 for an exactly flip-symmetric matrix;
+    1e-14 for the reference's phase-matrix builders on its direction grid)."""
+    return float(np.max(np.abs(W - W[::-1, ::-1])) / np.max(np.abs(W)))
+
+
+def symfold(W):
+    """(S, A), N x N each: S = (P + Q) / 2, A = (P - Q) / 2 with P[k, m] = (W[k, m] + W[k', m']) / 2 and
+    Q[k, m] = (W[k', m] + W[k, m']) / 2, k' = D-1-k, m' = D-1-m (k_symfold)."""
+    N = W.shape[0] // 2
+    F = W[::-1, ::-1]
+    p = W[:N, :N] + F[:N, :N]                  # W[k, m] + W[k', m']
+    q = W[::-1][:N, :N] + W[:, ::-1][:N, :N]   # W[k', m] + W[k, m']
+    return 0.25 * (p + q), 0.25 * (p - q)
+
+
+def source_symmetric(In_1, W):
+    """In_1 @ W for a flip-symmetric W as two N x N products: with a = In_1[:, :N], b = In_1[:, :N-1:-1] (mirrored),
+    X = (a + b) @ S, Y = (a - b) @ A:  Jn[:, m] = X + Y, Jn[:, D-1-m] = X - Y."""
+    N = W.shape[0] // 2
+    S, A = symfold(W)
+    a, b = In_1[:, :N], In_1[:, ::-1][:, :N]
+    X, Y = (a + b) @ S, (a - b) @ A
+    out = np.empty_like(In_1)
+    out[:, :N] = X + Y
+    out[:, ::-1][:, :N] = X - Y
+    return out

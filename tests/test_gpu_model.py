@@ -21,6 +21,9 @@ def test_single_slab(path):
     while "In_%d" % n in d:
         Jn = M.source_model(In_1, W, W, np.full(L, alb / 4), np.zeros(L))
         assert_close(Jn, d["Jn_%d" % n], ALG, "Jn")
+        # the flip-symmetric form of the contraction (two N x N products): same bar
+        assert M.asymmetry(W) <= 1e-12
+        assert_close(M.source_model(In_1, W, W, np.full(L, alb / 4), np.zeros(L), symmetric=True), d["Jn_%d" % n], ALG, "Jn (symmetric form)")
         In, st = M.transport_model(d["Jn_%d" % n], tau, mu, N, [(0, L - 1)], [M.a4b_count(tS, N)], None, 0.0)
         assert st == 0
         assert_close(In, d["In_%d" % n], ALG, "In")
@@ -28,8 +31,9 @@ def test_single_slab(path):
         n += 1
 
 
+@pytest.mark.parametrize("symmetric", [False, True], ids=["full", "symmetric"])
 @pytest.mark.parametrize("path", golden("g3_*.npz") + golden("g6_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
-def test_three_zone(path):
+def test_three_zone(path, symmetric):
     d, c = column_case(path)
     N, L, mu, tau = c["N"], c["L"], c["mu"], c["tau"]
     iu, idn = c["idx_up"], c["idx_down"]
@@ -40,6 +44,8 @@ def test_three_zone(path):
     ca[iu:idn + 1] *= fa
     cr[iu:idn + 1] = c["alb_aer"] / 4 * fr
     Wa, Wr = M.fold_weights(c["P_atm"], mu), M.fold_weights(c["P_aer"], mu)
+    if symmetric:     # every phase matrix of the reference has the symmetry to rounding
+        assert max(M.asymmetry(Wa), M.asymmetry(Wr)) <= 1e-12
     zones = [(0, iu - 1), (iu, idn), (idn + 1, L - 1)]
     nfix = [M.a4b_count(tau[iu - 1], N), M.a4b_count(tau[idn], N), M.a4b_count(tau[idn], N)]
     Isv = d["I_saved"]
@@ -47,7 +53,7 @@ def test_three_zone(path):
     tol = 5e-11 if c["surface"] == "lambertian" else ALG   # sign-alternating terms (H2) amplify rounding
     while O.convergence_ratio(In, I, N) >= 1e-4:
         n += 1
-        Jn = M.source_model(In_1, Wa, Wr, ca, cr)
+        Jn = M.source_model(In_1, Wa, Wr, ca, cr, symmetric=symmetric)
         In, st = M.transport_model(Jn, tau, mu, N, zones, nfix, c["surface"], c["grd_alb"])
         assert st == 0
         assert_close(In, Isv[n - 1], tol, "order %d" % n)
@@ -55,6 +61,25 @@ def test_three_zone(path):
         I = I + In
     assert n == c["n"]
     assert_close(I, d["I"], tol, "I")
+
+
+def test_symmetric_form_is_exact_on_a_symmetric_matrix_and_bounded_by_the_asymmetry():
+    """The two N x N products equal the full product for a flip-symmetric matrix (to rounding); for a matrix with an
+    asymmetric residual R the difference is the dropped term In_1 @ R -- the bound sosrt.h states."""
+    rng = np.random.default_rng(5)
+    N, L = 24, 9
+    D = 2 * N
+    G = rng.random((D, D))
+    Ws = 0.5 * (G + G[::-1, ::-1])
+    x = rng.random((L, D))
+    assert M.asymmetry(Ws) == 0.0
+    assert_close(M.source_symmetric(x, Ws), x @ Ws, 1e-14, "symmetric matrix")
+    R = 1e-9 * (G - G[::-1, ::-1])
+    W = Ws + R
+    diff = np.abs(M.source_symmetric(x, W) - x @ W)
+    bound = M.asymmetry(W) * np.max(np.abs(W)) * np.sum(np.abs(x), axis=1, keepdims=True)
+    assert np.all(diff <= bound * (1 + 1e-6) + 1e-15)
+    assert diff.max() > 1e-11          # (the test would be vacuous if the residual did nothing)
 
 
 def test_index_error_is_modelled():

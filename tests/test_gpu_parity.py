@@ -43,11 +43,44 @@ def test_source_function_is_the_dense_product(L, N, B):
     s = Solver(L, N, max_batch=B)
     s.set_grid(mu)
     s.set_phase(P)
+    asym, uses = s.phase_asymmetry()
+    assert asym > 0.1 and not uses                       # no flip symmetry: the full 2N x 2N product runs
     s.set_columns_single_slab(np.full(B, 0.5), alb, np.full(B, 0.3))
     J = s.source(X)
     for b in range(B):
         ref = O.Jn_NumInt(2, X[b], np.zeros(L), mu, 0.3, 0.5, P, alb[b], N)
         assert_close(J[b], ref, 1e-13, "Jn column %d" % b)
+    s.close()
+
+
+@pytest.mark.parametrize("L,N,B", [(50, 32, 1), (37, 100, 3), (200, 128, 2), (24, 256, 1), (21, 70, 2), (9, 6, 1)])
+def test_source_function_symmetric_form(L, N, B):
+    """A flip-symmetric matrix (P[m][k] = P[2N-1-m][2N-1-k], as every phase function of the scattering angle gives) that
+    is not symmetric under transposition: the library runs the two N x N products (jn_gemm.hip, SYM) and the result is
+    the reference's trapezoid sum; the forced full product gives the same to rounding."""
+    rng = np.random.default_rng(11 * N + L)
+    mu = inputs.direction_grid(N)
+    G = rng.uniform(0.2, 3.0, (2 * N, 2 * N))
+    P = G + G[::-1, ::-1]
+    assert np.abs(P - P.T).max() > 0.1
+    X = rng.uniform(0.0, 1.0, (B, L, 2 * N)) * np.linspace(0.5, 2.0, 2 * N)
+    alb = rng.uniform(0.5, 1.0, B)
+    s = Solver(L, N, max_batch=B)
+    s.set_grid(mu)
+    s.set_phase(P)
+    asym, uses = s.phase_asymmetry()
+    assert asym <= 1e-13 and uses           # (the rounding of the trapezoid weights of the grid)
+    s.set_columns_single_slab(np.full(B, 0.5), alb, np.full(B, 0.3))
+    J = s.source(X)
+    s.set_contraction("f64_full")
+    assert not s.phase_asymmetry()[1]
+    Jf = s.source(X)
+    s.set_contraction("f64")
+    assert np.array_equal(s.source(X), J)                # (switching back and forth leaves the folded matrices intact)
+    for b in range(B):
+        ref = O.Jn_NumInt(2, X[b], np.zeros(L), mu, 0.3, 0.5, P, alb[b], N)
+        assert_close(J[b], ref, 1e-13, "Jn column %d (symmetric form)" % b)
+        assert_close(Jf[b], ref, 1e-13, "Jn column %d (full product)" % b)
     s.close()
 
 
@@ -126,10 +159,14 @@ def test_index_error_like_the_reference():
 # ----------------------------------------------------------------------------------------------
 # column level against the reference (G3 specular, G6 Lambertian n >= 2, G4 digest at C2 shape)
 # ----------------------------------------------------------------------------------------------
-def _solve_fixture(c, I1=None, max_orders=64):
+def _solve_fixture(c, I1=None, max_orders=64, contraction=None):
     s = Solver(c["L"], c["N"], max_batch=1, max_orders=max_orders)
     s.set_grid(c["mu"])
     s.set_phase(c["P_atm"], c["P_aer"])
+    if contraction:
+        s.set_contraction(contraction)
+    else:                # the reference's phase matrices have the flip symmetry to rounding: the symmetric form is what runs
+        assert s.phase_asymmetry()[1]
     s.set_columns([c["idx_up"]], [c["idx_down"]], c["mu0"], c["grd_alb"], c["alb_atm"], c["alb_aer"], c["dtau_atm"],
                   c["dtau_aer"], c["tauStar_atm"] + c["tauStar_aer"], surface=c["surface"])
     r = s.solve(c["tau"][None], c["P0_atm"][None], c["P0_aer"][None], I1=None if I1 is None else I1[None], save_orders=True)
@@ -150,6 +187,25 @@ def test_specular_column_matches_reference(path, transport_mode):
     ofd, ofu = O.fluxes(d["I"], c["mu"], c["tau"], c["N"], c["mu0"], c["grd_alb"])
     assert_close(fd, ofd, 1e-12, "flux down")
     assert_close(fu, ofu, 1e-12, "flux up")
+
+
+@pytest.mark.parametrize("path", golden("g3_*.npz") + golden("g4_spec_C2_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
+def test_full_product_contraction_matches_reference_and_the_symmetric_form(path):
+    """SOSRT_CONTRACT_F64_FULL (the 2N x 2N product, what runs for matrices without the flip symmetry) against the same
+    goldens, and against the default symmetric form: same order counts, fields 1e-12 apart at most."""
+    d, c = column_case(path)
+    rf, _, _ = _solve_fixture(c, contraction="f64_full")
+    rs, _, _ = _solve_fixture(c)
+    assert rf.n[0] == c["n"] == rs.n[0]
+    if "I" in d:
+        assert_close(rf.I[0], d["I"], RTOL, "I (full product)")
+        for k in range(c["n"]):
+            assert_close(rf.I_saved[0, k], d["I_saved"][k], RTOL, "order %d (full product)" % (k + 1))
+    else:
+        N, L = c["N"], c["L"]
+        assert_close(rf.I[0, 0, N:], d["toa_up"], RTOL, "TOA up (full product)")
+        assert_close(rf.I[0].sum(axis=0), d["col_sum"], RTOL, "column sums (full product)")
+    assert_close(rs.I[0], rf.I[0], 1e-12, "symmetric form vs full product")
 
 
 @pytest.mark.parametrize("path", golden("g6_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
