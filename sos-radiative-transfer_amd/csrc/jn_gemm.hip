@@ -6,16 +6,23 @@
 // results of lane l are D[i = 4r + (l>>4)][j = l&15], r = 0..3.
 //
 // Workgroup tile: 64 rows x 128 columns, 4 waves, each wave 4x2 MFMA tiles (64 accumulator
-// registers).  Operands are staged through LDS in k-chunks of 32 with row strides chosen so that
-// the fragment reads (ds_read_b64) are bank-conflict free: A rows 34 doubles (68 dwords, 68/4 odd),
-// W rows 144 doubles (288 = 32 mod 64 dwords).  Two register buffers hold the global loads of the
-// next two chunks while the current one is multiplied (the loop is unrolled by two, so a buffer in
-// flight is never copied); a chunk is 64 MFMAs per wave = 4096 cycles of matrix pipe, which is
-// what hides the L2 / HBM latency of the loads, also when a workgroup is alone on its CU.
+// registers).  Operands are staged through LDS in k-chunks of GEMM_KC = 16 with row strides chosen so
+// that the fragment reads (ds_read_b64) are bank-conflict free: A rows 18 doubles, W rows 144 doubles
+// (288 = 32 mod 64 dwords).  The global loads of the next chunk are in registers while the current one
+// is multiplied (one chunk ahead in the dense tilings, four workgroups per CU hide the rest; two chunks
+// ahead in two register sets, loop unrolled by two, in the tail tiling, where a workgroup is alone on
+// its CU).
 //
-// Rows are addressed through row lists, so that one launch covers the plain rows (one pass over
-// W_atm) and the slab rows (two passes: W_atm then W_aer) without either writing the other's
-// rows; the per-row coefficient is applied to the A operand on its way into LDS.
+// Rows are addressed through row lists, so that one launch covers the plain rows (against W_atm) and the
+// slab rows (against the combined matrix ca W_atm + cr W_aer of their coefficient pair, one pass; two
+// passes, W_atm then W_aer, only when a batch has more distinct pairs than the cache of combined matrices)
+// without either writing the other's rows; the per-row coefficient is applied to the A operand on its way
+// into LDS.
+//
+// Two forms of the product (chosen per handle from the matrices, never from the batch): the full D x D
+// product, and -- when the folded matrices are flip-symmetric, as every phase function of the scattering
+// angle makes them -- two N x N products on the sum and the difference of a row's two halves (SYM below):
+// half the flops.
 #include "kernels.hpp"
 
 namespace sosrt {
