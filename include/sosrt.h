@@ -41,6 +41,7 @@ typedef struct sosrt_handle sosrt_t;
 #define SOSRT_COL_OK           0
 #define SOSRT_COL_INDEXERROR   1  /* upward mu->0+ search ran off the grid: the reference raises IndexError (spec:404, I1_In:103) */
 #define SOSRT_COL_MAXORDERS    2  /* not converged within max_orders                                                          */
+#define SOSRT_COL_INTERNAL     3  /* the transport kernel gave up waiting on itself (never expected; the column's field is unusable) */
 
 /* geometry of a column */
 #define SOSRT_GEOM_THREE_ZONE  0  /* above / inside / below the aerosol slab: SOS_Aer_main_specular.py:104-458 */

@@ -129,8 +129,12 @@ struct sosrt_handle {
     // convergence
     int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr, *d_erep = nullptr;
     unsigned long long* d_tauhash = nullptr;
-    int transport_mode = 2;              // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel (+ repair)
-    bool ring_ok = false;
+    // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel, 3 (default): the ring kernel for the
+    // orders below scan_from and the chunk-parallel kernel (transport_scan.hip) from there on, 4: the chunk-parallel kernel
+    // for every order.  The choice depends on the order index only, never on the live columns of the batch.
+    int transport_mode = 3;
+    int scan_from = 14;                  // SOSRT_SCAN_FROM: first order of the chunk-parallel kernel in mode 3
+    bool ring_ok = false, scan_ok = false;
     int gemm_tail_cols = 1 << 30;        // at or below this many live columns (and below the batch) tiles are laid over live columns (SOSRT_GEMM_TAIL)
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
     bool fast_ok = false;
@@ -402,7 +406,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_CONTRACT"))            // "full": the D x D product whatever the symmetry of the matrices
         if (strcmp(ev, "full") == 0) h->contraction = SOSRT_CONTRACT_F64_FULL;
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
-        h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : 1);
+        h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : (strcmp(ev, "scan") == 0 ? 4 : (strcmp(ev, "auto") == 0 ? 3 : 1)));
+    if (const char* ev = getenv("SOSRT_SCAN_FROM")) h->scan_from = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
@@ -617,6 +622,7 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
         if (h->g.nsmall)
             HIPCHK(hipMemcpy(h->d_small, h->plan.small_lanes.data(), h->g.nsmall * sizeof(int), hipMemcpyHostToDevice));
         h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
+        h->scan_ok = h->ring_ok && transport_scan_ok(h->g);
     }
     return 0;
 }
@@ -919,8 +925,8 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
         launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E, nullptr);
         HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E,
-                         (h->transport_mode == 2 && h->ring_ok) ? 3 : 1);
-        if (h->N - 3 > 61 && !(h->transport_mode == 2 && h->ring_ok))
+                         (h->transport_mode == 4 && h->scan_ok) ? 4 : ((h->transport_mode >= 2 && h->ring_ok) ? 3 : 1));
+        if (h->N - 3 > 61 && !(h->transport_mode >= 2 && h->ring_ok))
             launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 2);
     } else {
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, nullptr, 0);
@@ -988,7 +994,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     const int small_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;       // never equals an order tag
     bool small_published = false;
     const bool fast = h->transport_mode >= 1 && h->fast_ok && h->max_nz <= kRingZones;   // more zones: the general kernel
-    const int fast_mode = (h->transport_mode == 2 && h->ring_ok) ? 3 : 1;
+    const int ring_mode = (h->transport_mode >= 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) {
         // one attenuation table per distinct optical-depth profile
         launch_tau_groups(s, g, B, d_tau, h->d_tauhash, h->d_erep, h->d_nactive + sosrt_handle::kMaxGroups,
@@ -1097,8 +1103,10 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             if (fast) {
                 // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
                 // need not stage those rows either
+                // the kernel of this order: by the order index alone (a column's bits must not depend on its batch)
+                const int fast_mode = (h->scan_ok && (h->transport_mode == 4 || (h->transport_mode == 3 && n >= h->scan_from))) ? 4 : ring_mode;
                 Grid gt = g;
-                if (fast_mode == 3 && !h->need_small) gt.nsmall = 0;
+                if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0);
                 if (h->N - 3 > 61 && fast_mode == 1)     // register-streaming kernel: a search that leaves wave 0 is redone by the

@@ -1037,11 +1037,13 @@ void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, u
 template <int MAXT>
 static void launch_transport_t(hipStream_t s, dim3 grid, dim3 block, size_t shm, const TransportArgs& a, int mode) {
     // mode 0: general kernel, 1: wave-independent fast kernel, 2: general kernel repairing flagged columns,
-    // 3: the fast kernel's sweeps fed through an LDS ring
+    // 3: the fast kernel's sweeps fed through an LDS ring, 4: the chunk-parallel kernel (transport_scan.hip)
     if (mode == 1) {
         launch_transport_fast(s, grid, block, a);
     } else if (mode == 3) {
         launch_transport_ring(s, grid, a, g_ring_slots);
+    } else if (mode == 4) {
+        launch_transport_scan(s, grid, a);
     } else if (mode == 2) {
         if (a.accumulate) {
             if (a.saved) hipLaunchKernelGGL((k_transport<MAXT, true, true, true, true>), grid, block, shm, s, a);
@@ -1082,7 +1084,7 @@ void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, co
     const size_t shm = (size_t)(g.L + 2 * TC * (nt + 2) + 2 * nt + nt / 64 + 2) * sizeof(double);
     TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab, Etab ? erep : nullptr, g_transport_stamps};
     a.slots = ring_slots;
-    if (mode == 3 && accumulate && live > 0 && live < B && live_list) {       // ring kernel over the live columns only
+    if ((mode == 3 || mode == 4) && accumulate && live > 0 && live < B && live_list) {       // ring / scan kernel over the live columns only
         a.live = live;
         a.live_list = live_list;
         B = live;

@@ -123,6 +123,9 @@ void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const Transport
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
 bool transport_ring_ok(const Grid& g);
 void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots);
+// transport_scan.hip: the chunks of a sweep dealt to several waves (chunk-local recurrence + carried values)
+bool transport_scan_ok(const Grid& g);
+void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a);
 extern int g_ring_slots, g_ring_debug;                        // tuning (SOSRT_RING_SLOTS)
 extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
 

@@ -1,0 +1,887 @@
+// k_transport_scan: one order of transport (spec:326-449) with the chunks of a sweep dealt to several waves.
+//
+// The ring kernel (transport_ring.hip) gives a column two computing waves that walk the 2 L rows of an order one after
+// the other; a lone column is bound by the instruction stream of those waves (43-48 us per order whatever else runs on
+// the GPU), and the last twenty orders of a sweep are lone columns.  Only ONE operation per row is serial, the step of the
+// recurrence  D_t = E_t D_{t-1} + c_t;  the source terms, the mu -> 0 treatments, the running total and the stores are
+// row-local.  Here a chunk of TC = 8 rows is evaluated in its chunk-local form
+//     d_u = E_u d_{u-1} + c_u,   p_u = E_u p_{u-1}      (d_{-1} = 0, p_{-1} = 1: independent of every other chunk)
+//     D_u = fma(p_u, D_in, d_u),                          D_in = the value carried out of the previous chunk
+// so that the chunks of a sweep go round-robin to SW waves per lane group (64 directions), which work on their chunks
+// at once and hand the carried value on through LDS (one fma per chunk on the serial path instead of eight recurrence
+// steps plus everything else).  Chunks with a zone boundary, and the last chunk of a sweep, keep the serial form of the
+// ring kernel (state resets at zone ends, spec:359,378; blended restarts): they are single hops of the chain.
+//
+// The chunk-local form rounds differently from the serial one (1e-16 per step).  Which kernel transports an order is
+// therefore decided by the order index alone (api.hip: SOSRT_SCAN_FROM), never by how many columns of the batch are
+// live, so that a column's bits stay independent of its batch.
+//
+// Roles.  A workgroup is  nwc * SW computing waves (lane group x chunk residue)  +  SW loader waves.  The rows of Jn and
+// of the attenuation table reach the computing waves through LDS: a pool of NST stages, chunk g (0 .. 2 NCH - 1 over the two
+// sweeps) in stage g mod NST; loader w copies the chunks g = w, w + SW, ... (1-KiB half rows, `buffer_load_dwordx4 ... lds`)
+// as soon as the chunk that used the stage before has been taken out of it, and raises a flag; the computing waves take a
+// stage into registers and hand it back at once, so with NST > SW a residue's next chunk is on its way before the current
+// one is started (a chunk of 17 KiB takes some 4 000 cycles to arrive, more than a wave needs for a chunk).  A computing
+// wave loads only its rows of the running total itself, which it needs last, for its stores.  Everything is flag-driven
+// (LDS words polled by the waiting wave, plain accesses in program order: the LDS serves a wave's instructions in order),
+// no barrier inside a sweep; every poll is bounded (SOSRT_COL_INTERNAL on expiry, never expected).
+//
+// Measured (MI355X, lone column, L = 200, N = 128): 41-42 us per order against 48 for the ring kernel; in-kernel stamps
+// (-DSOSRT_SCAN_STAMPS, tools/stamps_scan.py): 35 us, of which a computing wave spends a third waiting (stage, carried value).
+#include <type_traits>
+
+#include "../../include/sosrt.h"
+#include "kernels.hpp"
+#include "transport_util.hpp"
+
+namespace sosrt {
+
+namespace {
+
+constexpr int SW = 4;                                      // waves per lane group = chunks of a sweep in flight
+constexpr int CR = 8;                                      // ring of carried values per lane group (> SW)
+constexpr int SROW = 128;                                  // doubles per staged row (one 1-KiB half row)
+constexpr int NST = 6;                                     // stages: chunk g (0 .. 2 NCH - 1 over the two sweeps) uses stage g mod NST
+constexpr int STAGE = (2 * TC + 1) * SROW;                 // doubles per stage: Jn, attenuation, + the Jn row before the chunk
+constexpr size_t kScanLdsBytes = 156 * 1024;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value arrives within a few thousand polls)
+
+template <bool ACC, bool SAVED>
+__global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fixcap) {
+    int b = blockIdx.x;
+    if (ACC && a.live > 0) {
+        b = a.live_list[blockIdx.x];
+        if (b < 0) return;                          // fewer live columns than the host's (lagging) count
+    } else if (ACC && !a.cv.active[b]) {
+        return;
+    }
+    const Grid& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int L = g.L, N = g.N, D = g.D;
+    const int nwc = (N + 63) >> 6;                             // lane groups
+    const int ncw = nwc * SW;                                  // computing waves; the SW loader waves follow
+    const bool loader = wid >= ncw;
+    const int lg = wid % nwc, grp = loader ? wid - ncw : wid / nwc;   // this wave: 64 directions, chunks grp, grp + SW, ...
+    const int dir = lg * 64 + lane;                            // downward direction dir, then upward direction N + dir
+    const bool valid = dir < N;
+    const int dirc = valid ? dir : N - 1;
+    const bool w0 = !loader && lg == 0;                        // holds the mu -> 0+ lanes
+    const bool wl = !loader && lg == ((N - 1) >> 6);           // holds the mu -> 0- lanes
+    const int nwaves = blockDim.x >> 6;
+    const int NCH = (L + TC - 1) / TC;
+
+#ifdef SOSRT_SCAN_STAMPS    // diagnostic builds: cycle stamps of the first and the last wave, [b][2][8] (tools/stamps_scan.py)
+    unsigned long long t_wait = 0, t_stage = 0;
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if (a.stamps && lane == 0 && (wid == 0 || wid == ncw - 1))
+            a.stamps[((size_t)b * 2 + (wid == 0 ? 0 : 1)) * 8 + i] = i == 6 ? t_wait : (i == 7 ? t_stage : clock64());
+    };
+#else
+    auto stamp = [](int) {};
+#endif
+    stamp(0);
+    extern __shared__ double sm[];
+    double* s_stage = sm;                                      // [NST][STAGE] rows of the chunks in flight
+    double* s_carry = s_stage + (size_t)NST * STAGE;            // [nwc][CR][64] ring of the values carried into the chunks
+    double* s_sfc = s_carry + (size_t)nwc * CR * 64;           // [nwc * 64] surface row by downward direction
+    double* s_fixc = s_sfc + nwc * 64;                         // [kRingZones][fixcap][kFixMaxSrc] compact extrapolation tables
+    double* s_red = s_fixc + kRingZones * fixcap * kFixMaxSrc; // [nwaves + 2]
+    double* s_hd = s_red + nwaves + 2;                         // [L + 1] half layer thicknesses
+    double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
+    double* s_prmu = s_S + (size_t)g.nsmall * L;               // [16] 1/mu of the first upward directions
+    double* s_conv = s_prmu + 16;                              // [4][nwc * 64] last rows of the sweeps: value, running total
+    double* s_xw = s_conv + 4 * nwc * 64;                      // [ncw][2][TC * 16] per-wave exchange: values, running totals
+    // flags (ints): [nwc][CR] sequence number of the carried value in a slot, [NST] chunk landed in a stage,
+    // [NST][nwc] chunk taken out of a stage by a lane group (chunk numbers g + 1)
+    int* s_flagq = reinterpret_cast<int*>(s_xw + (size_t)ncw * 2 * TC * 16);
+    int* s_landed = s_flagq + nwc * CR;
+    int* s_taken = s_landed + NST;
+    __shared__ int s_flag[3];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] internal
+    double* s_x = s_xw + (size_t)(loader ? 0 : wid) * 2 * TC * 16;
+    double* s_xI = s_x + TC * 16;
+    const int xb_dn = max(((N - 1) & 63) - 15, 0);
+
+    const ColDesc* __restrict__ dg = a.desc + b;
+    const int nz = dg->nz;
+    const int zend0 = nz > 1 ? dg->r1[0] : -9, zend1 = nz > 2 ? dg->r1[1] : -9;
+    const int zbeg1 = nz > 1 ? dg->r0[1] : -9, zbeg2 = nz > 2 ? dg->r0[2] : -9;
+    const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
+    const int surface = dg->surface;
+    const double rho = dg->rho;
+    const int fbytes = L * D * 8, RB = D * 8;
+    const __amdgpu_buffer_rsrc_t rJ = make_rsrc(a.Jn + (size_t)b * L * D, fbytes);
+    const __amdgpu_buffer_rsrc_t rE = make_rsrc(a.Etab + (size_t)(a.erep ? a.erep[b] : b) * L * D, fbytes);
+    const __amdgpu_buffer_rsrc_t rIn = make_rsrc(a.In + (size_t)b * L * D, fbytes);
+    const __amdgpu_buffer_rsrc_t rI = make_rsrc(ACC ? a.I + (size_t)b * L * D : a.In, ACC ? fbytes : 0);
+    (void)rJ; (void)rE;
+    const __amdgpu_buffer_rsrc_t rS = make_rsrc(SAVED ? a.saved + (size_t)b * a.saved_col_stride : a.In, SAVED ? fbytes : 0);
+
+    // chunks with a zone boundary and the last chunk of each sweep: serial form (one bit per chunk of a sweep)
+    unsigned long long sp_dn = 1ull << (NCH - 1), sp_up = sp_dn;
+    {
+        const int zr[4] = {zend0, zend1, zbeg1, zbeg2};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (zr[i] >= 0) {
+                sp_dn |= 1ull << (zr[i] / TC);
+                sp_up |= 1ull << ((L - 1 - zr[i]) / TC);
+            }
+    }
+
+    // ---- per-column tables ----
+    {
+        const int nt = blockDim.x;
+        for (int zz = 0; zz < kRingZones; ++zz) {
+            const FixTab& src = g.fix[dg->fixtab[zz]];
+            for (int i = tid; i < fixcap * kFixMaxSrc; i += nt) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
+        }
+        if (tid < 3) s_flag[tid] = 0;
+        for (int i = tid; i < nwc * CR + NST + NST * nwc; i += nt) s_flagq[i] = 0;
+        const double* __restrict__ tau = a.tau + (size_t)b * L;
+        for (int t = tid; t <= L; t += nt) s_hd[t] = (t == 0 || t == L) ? 0.0 : (tau[t] - tau[t - 1]) * 0.5;
+        if (tid < 16) s_prmu[tid] = (tid > 0 && tid < N) ? 1.0 / g.mu[N + tid] : 0.0;
+        const double* __restrict__ In0 = a.In + (size_t)b * L * D;
+        for (int i = tid; i < g.nsmall * L; i += nt) {
+            const int k = i / L, t = i - k * L;
+            s_S[i] = In0[(size_t)t * D + g.small_lanes[k]];
+        }
+    }
+    __syncthreads();
+    stamp(1);
+
+    // The value carried into chunk q of this lane group, published by the wave of chunk q - 1.  Plain LDS accesses in
+    // program order, no atomics: the LDS serves a wave's instructions in order, so a flag written after the value is seen
+    // after the value; a release / acquire pair at workgroup scope would also wait for the wave's global loads and stores
+    // (s_waitcnt vmcnt(0)) -- a memory round trip on every hop of the chain.
+    typedef __attribute__((address_space(3))) volatile int lds_vint;          // (explicit LDS pointers: a generic pointer would
+    typedef __attribute__((address_space(3))) volatile double lds_vdouble;    //  make these FLAT accesses, which count in vmcnt)
+    lds_vint* const l_flagq = (lds_vint*)(s_flagq + lg * CR);
+    lds_vdouble* const l_carry = (lds_vdouble*)(s_carry + (size_t)lg * CR * 64 + lane);
+    lds_vint* const l_landed = (lds_vint*)s_landed;
+    lds_vint* const l_taken = (lds_vint*)s_taken;
+    auto spin = [&](lds_vint* f, int want) __attribute__((always_inline)) {
+#ifdef SOSRT_SCAN_STAMPS
+        const unsigned long long w0_ = clock64();
+#endif
+        unsigned it = 0;
+        while (*f != want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++it > kSpinLimit) { s_flag[2] = 1; break; }      // (never: every wave of the workgroup is resident)
+        }
+#ifdef SOSRT_SCAN_STAMPS
+        t_wait += clock64() - w0_;
+#endif
+    };
+    // `cs` = sequence number of the chunk in this lane group's chain (1 .. 2 NCH over the two sweeps)
+    auto wait_carry = [&](int cs) __attribute__((always_inline)) -> double {
+        spin(l_flagq + (cs & (CR - 1)), cs);
+        return l_carry[(cs & (CR - 1)) * 64];
+    };
+    auto publish = [&](int cs, double val) __attribute__((always_inline)) {
+        l_carry[(cs & (CR - 1)) * 64] = val;
+        if (lane == 0) l_flagq[cs & (CR - 1)] = cs;
+    };
+    // The rows of chunk g (0 .. NCH-1: downward, NCH ..: upward) out of its stage (the loader has raised the flag), and the
+    // stage back to the loaders at once.  The LDS serves the reads before the word that follows them.  The running total
+    // does not go through the stage (LDS): the wave asks for its rows itself here and needs them only for its stores.
+    auto take = [&](int gq, int vo_, int so0, int dso, double (&J)[TC], double (&E)[TC], double (&I)[TC], double& Jx) __attribute__((always_inline)) {
+        const int stg = gq % NST;
+#ifdef SOSRT_SCAN_STAMPS
+        const unsigned long long tw_ = t_wait;
+#endif
+        spin(l_landed + stg, gq + 1);
+#ifdef SOSRT_SCAN_STAMPS
+        t_stage += t_wait - tw_; t_wait = tw_;
+#endif
+        typedef __attribute__((address_space(3))) double lds_double;
+        const lds_double* st = (const lds_double*)(s_stage + (size_t)stg * STAGE + dirc);
+        asm volatile("" ::: "memory");                      // (compiler only: the reads stay between the two flag accesses)
+#pragma unroll
+        for (int u = 0; u < TC; ++u) {
+            J[u] = st[(0 * TC + u) * SROW];
+            E[u] = st[(1 * TC + u) * SROW];
+        }
+        Jx = st[(2 * TC) * SROW];
+        asm volatile("" ::: "memory");
+        if (lane == 0) l_taken[stg * nwc + lg] = gq + 1;
+#pragma unroll
+        for (int u = 0; u < TC; ++u) I[u] = ACC ? bload(rI, vo_, min(max(so0 + u * dso, 0), (L - 1) * RB)) : 0.0;
+    };
+
+    // ------------------------------- loader side -------------------------------
+    auto issue = [&](int gq) __attribute__((always_inline)) {
+        const bool up = gq >= NCH;
+        const int q = up ? gq - NCH : gq;
+        double* dst = s_stage + (size_t)(gq % NST) * STAGE;
+        const int t0 = up ? L - 1 - q * TC : q * TC;
+        const int half = up ? N * 8 : 0;
+        const int vo = lane * 16;
+#pragma unroll
+        for (int u = 0; u < TC; ++u) {
+            const int row = up ? max(t0 - u, 0) : min(t0 + u, L - 1);
+            const int so = row * RB + half;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROW), 16, vo, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROW), 16, vo, so, 0, 0);
+        }
+        const int rx = up ? min(t0 + 1, L - 1) : max(t0 - 1, 0);     // the row before the chunk (unused by the first chunk)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROW), 16, vo, rx * RB + half, 0, 0);
+    };
+    // Loader `grp` carries the chunks g = grp, grp + SW, ... of both sweeps.  Chunk g goes into stage g mod NST once every
+    // lane group has taken chunk g - NST out of it: with NST > SW a residue's next chunk is requested before its current
+    // one is even started.
+    auto load_chunks = [&](int g0, int g1) __attribute__((always_inline)) {
+        for (int gq = g0; gq < g1; gq += SW) {
+            if (gq >= NST)
+                for (int i = 0; i < nwc; ++i) spin(l_taken + (gq % NST) * nwc + i, gq - NST + 1);
+            issue(gq);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) l_landed[gq % NST] = gq + 1;
+        }
+    };
+    // the chunks a loader may carry before the turn-round: those whose stage was last used by a downward chunk
+    const int g_seam = min(NCH + NST, 2 * NCH);
+    int g_next = grp;                                           // (loaders)
+
+    const double mu_up = (valid && dir > 0) ? g.mu[N + dirc] : 1.0;
+    // Transposed work items for the two mu -> 0 treatments: lane = 8 * (row of the chunk) + (position).
+    const int uT = lane >> 3, pT = lane & 7;
+    const double muT = (pT + 1 < N) ? g.mu[N + pT + 1] : 1.0;          // upward direction N + pT + 1
+    const double* xrow = s_x + uT * 16;
+    double Bv = 0;
+
+    // =============================== downward ===============================
+    if (loader) {
+        // the chunks of the downward sweep and, across the seam, the first ones of the upward sweep
+        load_chunks(g_next, g_seam);
+        while (g_next < g_seam) g_next += SW;
+    } else {
+        const int m = dirc;
+        const int vo = m * 8;
+        const double mu = g.mu[m];
+        const bool tr = valid && m <= N - 2;
+        const bool small = tr && fabs(mu) < kMuThreshold;       // spec:333
+        const bool stdl = tr && !small;
+        const double nrmu = stdl ? -1.0 / mu : 0.0;
+        const bool has_small = wl && g.nsmall > 0;
+        const int sbase = small ? (m - g.small_lanes[0]) * L : 0;   // the small lanes are consecutive directions
+        const int lmT = ((N - 1) & 63) - pT;                        // lane of direction N-1-pT in the wave that holds it
+        auto zone_of = [&](int t) __attribute__((always_inline)) { return (zbeg2 >= 0 && t >= zbeg2) ? 2 : ((zbeg1 >= 0 && t >= zbeg1) ? 1 : 0); };
+        // (by shifts: a chain of selects over the three captured counts becomes a table of pointers on the stack, read back
+        // with FLAT loads that wait for every global load and store in flight)
+        const int nfix_packed = nfix0 | (nfix1 << 10) | (nfix2 << 20);
+        auto nfix_of = [&](int zz) __attribute__((always_inline)) { return (nfix_packed >> (10 * zz)) & 1023; };
+        // one chunk: rows t0 .. t0 + TC - 1
+        auto chunk = [&](auto special_t, auto mode_t, int q) __attribute__((always_inline)) {
+            constexpr bool SP = decltype(special_t)::value;
+            constexpr int MODE = decltype(mode_t)::value;
+            const int t0 = q * TC;
+            double Jc[TC], Ec[TC], Ic[TC], Jx_;
+            take(q, vo, t0 * RB, RB, Jc, Ec, Ic, Jx_);
+            const double Jprev = q > 0 ? Jx_ : 0.0;
+            // extrapolation table of the zone (In_limit:113-141 as a linear map): chunk-local copies
+            double c[kFixMaxSrc] = {0, 0, 0, 0, 0};
+            double cT[kFixMaxSrc] = {0, 0, 0, 0, 0};           // row pT of the table: work item (uT, pT) rewrites direction N-1-pT
+            int sl[kFixMaxSrc] = {0, 0, 0, 0, 0};
+            int nfx = 0;
+            bool fixlane = false;
+            auto load_fix = [&](int zz) __attribute__((always_inline)) {
+                const double* ftC = s_fixc + zz * fixcap * kFixMaxSrc;
+                nfx = nfix_of(zz);
+                const int ns = nfx < 2 ? 2 : (nfx < kFixMaxSrc ? nfx : kFixMaxSrc);     // In_limit:118-141
+                fixlane = valid && nfx > 0 && m >= N - nfx;
+                const int i = fixlane ? N - 1 - m : 0;
+                const int s0 = nfx < 2 ? N - nfx - 2 : N - nfx - ns;
+#pragma unroll
+                for (int k = 0; k < kFixMaxSrc; ++k) {
+                    if (SP || MODE == 2) c[k] = (fixlane && k < ns) ? ftC[i * ns + min(k, ns - 1)] : 0.0;     // (incl. the fast special form)
+                    if (!SP) cT[k] = (pT < nfx && k < ns) ? ftC[pT * ns + min(k, ns - 1)] : 0.0;
+                    sl[k] = (s0 + min(k, ns - 1)) & 63;
+                }
+            };
+            if (wl && ((SP && MODE != 3) || (!SP && MODE != 0))) load_fix(zone_of(t0));
+            double cc[TC], v[TC], Sc[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) Sc[u] = 0;
+            if (((SP && MODE != 3) || MODE == 2) && has_small) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const double sv = s_S[sbase + min(t0 + u, L - 1)];
+                    Sc[u] = small ? sv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = SP ? min(t0 + u, L - 1) : t0 + u;
+                const double hk = s_hd[t];
+                const double Jp = u == 0 ? Jprev : Jc[u - 1];
+                cc[u] = rec_src(rec_hr(hk, nrmu), Jp, Ec[u], Jc[u]);
+            }
+            if (!SP) {
+                // chunk-local form, then the carried value
+                double dl[TC], pl[TC];
+                {
+                    double d = 0, p = 1;
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        d = rec_step(d, Ec[u], cc[u]);
+                        p = u == 0 ? Ec[0] : rec_hr(p, Ec[u]);
+                        dl[u] = d; pl[u] = p;
+                    }
+                }
+                const double Din = q == 0 ? 0.0 : wait_carry(q);
+                publish(q + 1, rec_step(Din, pl[TC - 1], dl[TC - 1]));      // on at once: the next chunk's wave waits for it
+#pragma unroll
+                for (int u = 0; u < TC; ++u) v[u] = rec_step(Din, pl[u], dl[u]);
+                if (MODE == 2 && has_small) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) v[u] = rec_add(v[u], Sc[u]);
+                }
+                // Up to 8 rewritten directions: the chunk goes through LDS and work item (uT, pT) does row uT, direction N-1-pT.
+                const bool tfix = MODE == 1 || (MODE == 2 && wl && nfx > 0 && nfx <= 8 && sl[0] >= xb_dn);   // sources inside the 16-lane window
+                if (tfix) {
+                    if (lane >= xb_dn && lane < xb_dn + 16) {
+#pragma unroll
+                        for (int u = 0; u < TC; ++u) {
+                            s_x[u * 16 + lane - xb_dn] = v[u];
+                            if (ACC) s_xI[u * 16 + lane - xb_dn] = Ic[u];
+                        }
+                    }
+                    double acc = 0;
+#pragma unroll
+                    for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(cT[k], xrow[max(sl[k] - xb_dn, 0)], acc);
+                    const int mT = N - 1 - pT;
+                    const double IcT = ACC ? s_xI[uT * 16 + min(max(lmT - xb_dn, 0), 15)] : 0.0;
+                    if (pT < nfx) {
+                        const int voT = (t0 + uT) * RB + mT * 8;
+                        bstore(rIn, voT, 0, acc);
+                        if (ACC) bstore(rI, voT, 0, IcT + acc);
+                        if (SAVED) bstore(rS, voT, 0, acc);
+                    }
+                } else if (MODE == 2 && wl && nfx > 0) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        double acc = 0;
+#pragma unroll
+                        for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(c[k], readlane_f64(v[u], sl[k]), acc);
+                        v[u] = fixlane ? acc : v[u];
+                    }
+                }
+                if (valid && !(tfix && fixlane)) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        const int so = (t0 + u) * RB;
+                        bstore(rIn, vo, so, v[u]);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
+                        if (SAVED) bstore(rS, vo, so, v[u]);
+                    }
+                }
+            } else if (MODE == 3) {
+                // A chunk with a zone boundary (or the last one) when every rewritten direction can go through the transposed
+                // work items: the serial part is the recurrence alone -- the extrapolation is evaluated in line only for the
+                // row at a zone end, whose final value is the state of the next zone (spec:359,378) -- and the carried value
+                // leaves before the treatments and the stores.  Same operations per element as the general form below.
+                double Dv = q == 0 ? 0.0 : wait_carry(q);
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 + u;
+                    const double Dn = rec_step(Dv, Ec[u], cc[u]);
+                    v[u] = Dn;
+                    const bool zone_end = t == zend0 || t == zend1;
+                    double x = Dn;
+                    if (zone_end && wl) {
+                        load_fix(zone_of(t));
+                        if (nfx > 0) {
+                            double acc = 0;
+#pragma unroll
+                            for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(c[k], readlane_f64(Dn, sl[k]), acc);
+                            x = fixlane ? acc : Dn;
+                        }
+                    }
+                    Dv = t < L ? (zone_end ? (stdl ? x : 0.0) : Dn) : Dv;
+                }
+                if (q + 1 < NCH) publish(q + 1, Dv);
+                if (wl) {
+                    if (lane >= xb_dn && lane < xb_dn + 16) {
+#pragma unroll
+                        for (int u = 0; u < TC; ++u) {
+                            s_x[u * 16 + lane - xb_dn] = v[u];
+                            if (ACC) s_xI[u * 16 + lane - xb_dn] = Ic[u];
+                        }
+                    }
+                    // work item (uT, pT): row t0 + uT with the table of that row's zone
+                    const int tT = t0 + uT;
+                    const int zT = zone_of(min(tT, L - 1)), nfT = nfix_of(zT);
+                    const int nsT = nfT < 2 ? 2 : (nfT < kFixMaxSrc ? nfT : kFixMaxSrc);
+                    const int s0T = nfT < 2 ? N - nfT - 2 : N - nfT - nsT;
+                    const double* ftT = s_fixc + zT * fixcap * kFixMaxSrc;
+                    double acc = 0;
+#pragma unroll
+                    for (int k = 0; k < kFixMaxSrc; ++k) {
+                        const double ck = (pT < nfT && k < nsT) ? ftT[pT * nsT + min(k, nsT - 1)] : 0.0;
+                        const int sk = ((s0T + min(k, nsT - 1)) & 63) - xb_dn;
+                        acc = fix_acc(ck, xrow[max(sk, 0)], acc);
+                    }
+                    const int mT = N - 1 - pT;
+                    const double IcT = ACC ? s_xI[uT * 16 + min(max(lmT - xb_dn, 0), 15)] : 0.0;
+                    if (pT < nfT && tT < L) {
+                        const int voT = tT * RB + mT * 8;
+                        bstore(rIn, voT, 0, acc);
+                        if (ACC) bstore(rI, voT, 0, IcT + acc);
+                        if (SAVED) bstore(rS, voT, 0, acc);
+                        if (tT == L - 1) {
+                            s_sfc[mT] = acc;
+                            s_conv[0 * nwc * 64 + mT] = acc;
+                            s_conv[1 * nwc * 64 + mT] = IcT + acc;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 + u;
+                    const int nfu = wl ? nfix_of(zone_of(min(t, L - 1))) : 0;
+                    const bool fixu = nfu > 0 && m >= N - nfu;
+                    if (valid && !fixu && t < L) {
+                        const int so = t * RB;
+                        bstore(rIn, vo, so, v[u]);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
+                        if (SAVED) bstore(rS, vo, so, v[u]);
+                        if (t == L - 1) {
+                            s_sfc[dir] = v[u];
+                            s_conv[0 * nwc * 64 + dir] = v[u];
+                            s_conv[1 * nwc * 64 + dir] = Ic[u] + v[u];
+                        }
+                    }
+                }
+            } else {
+                // serial form (as the ring kernel): zone boundaries, last chunk
+                double Dv = q == 0 ? 0.0 : wait_carry(q);
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 + u;
+                    if (wl && (t == zbeg1 || t == zbeg2)) load_fix(t == zbeg1 ? 1 : 2);
+                    const double Dn = rec_step(Dv, Ec[u], cc[u]);
+                    double x = has_small ? rec_add(Dn, Sc[u]) : Dn;
+                    if (wl && nfx > 0) {
+                        double acc = 0;
+#pragma unroll
+                        for (int k = 0; k < kFixMaxSrc; ++k) acc = fix_acc(c[k], readlane_f64(x, sl[k]), acc);
+                        x = fixlane ? acc : x;
+                    }
+                    v[u] = x;
+                    const bool zone_end = t == zend0 || t == zend1;     // the next zone starts from the final row (spec:359,378)
+                    Dv = t < L ? (zone_end ? (stdl ? x : 0.0) : Dn) : Dv;
+                    if (valid && t < L) {
+                        const int so = t * RB;
+                        bstore(rIn, vo, so, x);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + x);
+                        if (SAVED) bstore(rS, vo, so, x);
+                    }
+                }
+                if (q + 1 < NCH) publish(q + 1, Dv);
+                if (t0 + TC >= L) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u)
+                        if (t0 + u == L - 1 && valid) {
+                            s_sfc[dir] = v[u];
+                            s_conv[0 * nwc * 64 + dir] = v[u];
+                            s_conv[1 * nwc * 64 + dir] = Ic[u] + v[u];
+                        }
+                }
+            }
+        };
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
+        using M3 = std::integral_constant<int, 3>;
+        for (int q = grp; q < NCH; q += SW) {
+            if ((sp_dn >> q) & 1) {
+                // fast form when every zone the chunk touches has at most 8 rewritten directions with their sources inside the
+                // 16-lane window (and no |mu| < 0.01 lane keeps its k_smallmu value)
+                bool fastsp = !has_small;
+                if (wl) {
+                    const int za = zone_of(q * TC), zb = zone_of(min(q * TC + TC - 1, L - 1));
+                    for (int zz = za; zz <= zb; ++zz) {
+                        const int nf = nfix_of(zz);
+                        const int ns = nf < 2 ? 2 : (nf < kFixMaxSrc ? nf : kFixMaxSrc);
+                        const int sl0 = (nf < 2 ? N - nf - 2 : N - nf - ns) & 63;
+                        fastsp = fastsp && nf <= 8 && (nf == 0 || sl0 >= xb_dn);
+                    }
+                }
+#ifdef SOSRT_SCAN_GENERAL_SPECIAL
+                fastsp = false;
+#endif
+                if (fastsp) chunk(std::true_type{}, M3{}, q);
+                else chunk(std::true_type{}, M2{}, q);
+            } else {
+                // MODE: 0 this wave has no treated lane here, 1 the transposed extrapolation alone, 2 anything else
+                const int nfx = nfix_of(zone_of(q * TC));
+                const int ns = nfx < 2 ? 2 : (nfx < kFixMaxSrc ? nfx : kFixMaxSrc);
+                const int sl0 = (nfx < 2 ? N - nfx - 2 : N - nfx - ns) & 63;
+                const int mode = (!wl || (nfx == 0 && !has_small)) ? 0 : ((!has_small && nfx <= 8 && sl0 >= xb_dn) ? 1 : 2);
+                if (mode == 0) chunk(std::false_type{}, M0{}, q);
+                else if (mode == 1) chunk(std::false_type{}, M1{}, q);
+                else chunk(std::false_type{}, M2{}, q);
+            }
+        }
+    }
+    stamp(2);
+    __syncthreads();                                            // the surface row is complete
+    stamp(3);
+
+    // =============================== surface ===============================
+    if (surface == SOSRT_SURFACE_SPECULAR) {
+        Bv = valid ? rho * s_sfc[N - 1 - dir] : 0.0;                // spec:397
+    } else if (surface == SOSRT_SURFACE_LAMBERTIAN || surface == SOSRT_SURFACE_LAMBERTIAN_README) {
+        // -2 rho trapz(In[L-1, rev] mu[rev], mu[rev]), rev = N-2 .. 0   (lam:399), descending abscissae
+        double term = 0;
+        if (dir <= N - 3) {
+            const int k0 = N - 2 - dir, k1 = k0 - 1;
+            const double x0 = g.mu[k0], x1 = g.mu[k1];
+            term = (x1 - x0) * (s_sfc[k1] * x1 + s_sfc[k0] * x0) / 2;
+        }
+        const double ws = wave_sum_(term);
+        if (grp == 0 && lane == 0) s_red[lg] = ws;
+        __syncthreads();
+        double S = 0;
+        for (int i = 0; i < nwc; ++i) S += s_red[i];
+        Bv = (surface == SOSRT_SURFACE_LAMBERTIAN_README ? 2 : -2) * rho * S;          // lam:399 as coded (negative), or README.md:215
+    }
+
+    // =============================== upward ===============================
+    if (loader) {
+        load_chunks(g_next, 2 * NCH);
+    } else {
+        const int mj = N + dirc;
+        const int vo = mj * 8;
+        const bool tr = valid && dir > 0;
+        const double mu = mu_up;
+        const double prmu = tr ? 1.0 / mu : 0.0;
+        const int last_cand = min(N - 3, 61);
+        bool notfound = false;
+        // spec:401-409 for one row held across the first lane group: x is the raw row, returns the blended value
+        auto blend = [&](double x) __attribute__((always_inline)) {
+            const double x1 = lane_up1(x), x2 = lane_up1(x1);
+            const bool stop = lane >= 1 && lane <= last_cand && !(fabs((x - x1) - (x1 - x2)) > 0.0001);
+            const unsigned long long mk = __ballot(stop);
+            const int kf = mk ? __ffsll((long long)mk) : 1;
+            notfound |= (mk == 0);
+            const double r0 = readlane_f64(x, 0), rk = readlane_f64(x, kf);
+            const double w = blend_weight(mu, readlane_f64(prmu, kf));         // mu_m / mu_kf
+            const double bl = blend_val(w, r0, rk);
+            return (tr && dir < kf) ? bl : x;
+        };
+        // one chunk: rows t0, t0 - 1, ..., t0 - TC + 1
+        // SP, MODE: plain chunk 0 (no mu -> 0+ lanes in this wave) / 1 (first lane group); chunk with a zone boundary or last
+        // chunk: 1 general form, 2 / 3 fast form without / with the mu -> 0+ lanes
+        auto chunk = [&](auto special_t, auto mode_t, int j) __attribute__((always_inline)) {
+            constexpr bool SP = decltype(special_t)::value;
+            constexpr int MODE = decltype(mode_t)::value;
+            constexpr bool FAST = SP && MODE >= 2;
+            constexpr int PM = FAST ? MODE - 2 : MODE;          // treatment of the rows: 0 none, 1 transposed blend
+            const int t0 = L - 1 - j * TC;
+            double Jc[TC], Ec[TC], Ic[TC], Jx_;
+            take(NCH + j, vo, t0 * RB, -RB, Jc, Ec, Ic, Jx_);
+            const double Jnext = j > 0 ? Jx_ : 0.0;
+            double cc[TC], v[TC];
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int t = SP ? max(t0 - u, 0) : t0 - u;
+                const double hk = s_hd[t + 1];
+                const double Jx = u == 0 ? Jnext : Jc[u - 1];
+                const double src = rec_src(rec_hr(hk, prmu), Jx, Ec[u], Jc[u]);
+                // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
+                cc[u] = (SP && (t == zend0 || t == zend1)) ? 0.0 : src;
+            }
+            if (!SP || FAST) {
+                if (!SP) {
+                    double dl[TC], pl[TC];
+                    {
+                        double d = 0, p = 1;
+#pragma unroll
+                        for (int u = 0; u < TC; ++u) {
+                            d = rec_step(d, Ec[u], cc[u]);
+                            p = u == 0 ? Ec[0] : rec_hr(p, Ec[u]);
+                            dl[u] = d; pl[u] = p;
+                        }
+                    }
+                    const double Uin = j == 0 ? Bv : wait_carry(NCH + j);
+                    publish(NCH + j + 1, rec_step(Uin, pl[TC - 1], dl[TC - 1]));      // on at once: the next chunk's wave waits for it
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) v[u] = rec_step(Uin, pl[u], dl[u]);
+                } else {
+                    // fast form of a chunk with a zone boundary (or the last one): the serial part is the recurrence alone; the
+                    // search and blend are evaluated in line only for the first row of a zone, whose blended value is the
+                    // state of the zone above; the carried value leaves before the treatments and the stores
+                    double U = j == 0 ? Bv : wait_carry(NCH + j);
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        const int t = t0 - u;
+                        const double Un = rec_step(U, Ec[u], cc[u]);
+                        v[u] = Un;
+                        const bool zone_start = t == zbeg1 || t == zbeg2;
+                        double x = Un;
+                        if (zone_start && w0) x = blend(dir == 0 ? Jc[u] : Un);
+                        U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
+                    }
+                    if (j + 1 < NCH) publish(NCH + j + 1, U);
+                }
+                // spec:401-409: the chunk goes through LDS and work item (uT, pT) tests candidate k = pT+1 of row uT, then
+                // produces direction N+k of that row (blended below the stop, raw above it).  A row whose search goes
+                // beyond 8 candidates sends the chunk through the row-by-row path.
+                bool tblend = false;
+                if (PM == 1) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) v[u] = dir == 0 ? Jc[u] : v[u];                  // spec:401
+                    if (lane < 16) {
+#pragma unroll
+                        for (int u = 0; u < TC; ++u) {
+                            s_x[u * 16 + lane] = v[u];
+                            if (ACC) s_xI[u * 16 + lane] = Ic[u];
+                        }
+                    }
+                    const int k = pT + 1;
+                    const double xa = xrow[k], xb = xrow[k + 1], xc = xrow[k + 2];
+                    const bool stop = (k <= last_cand) & !(fabs((xa - xb) - (xb - xc)) > 0.0001);
+                    const unsigned long long mk = __ballot(stop);
+                    const unsigned bits = (unsigned)(mk >> (8 * uT)) & 0xffu;    // the candidates of this row
+                    tblend = __ballot(bits != 0) == ~0ull;
+                    if (tblend) {
+                        const int kf = __ffs((int)bits) + 1;                     // ks + 1, <= 9
+                        const double r0 = xrow[0], rk = xrow[kf];
+                        const double w = blend_weight(muT, s_prmu[kf]);              // mu_m / mu_kf
+                        const double bl = blend_val(w, r0, rk);
+                        const double val = k < kf ? bl : xa;
+                        const double IcT = ACC ? s_xI[uT * 16 + k] : 0.0;
+                        if (k < N && (!SP || t0 - uT >= 0)) {
+                            const int voT = (t0 - uT) * RB + (N + k) * 8;
+                            bstore(rIn, voT, 0, val);
+                            if (ACC) bstore(rI, voT, 0, IcT + val);
+                            if (SAVED) bstore(rS, voT, 0, val);
+                            if (SP && t0 - uT == 0) {
+                                s_conv[2 * nwc * 64 + k] = val;
+                                s_conv[3 * nwc * 64 + k] = IcT + val;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < TC; ++u) {
+                            const double xb_ = blend(v[u]);
+                            if (valid && (!SP || t0 - u >= 0)) {
+                                const int so = (t0 - u) * RB;
+                                bstore(rIn, vo, so, xb_);
+                                if (ACC) bstore(rI, vo, so, Ic[u] + xb_);
+                                if (SAVED) bstore(rS, vo, so, xb_);
+                                if (SP && t0 - u == 0) {
+                                    s_conv[2 * nwc * 64 + dir] = xb_;
+                                    s_conv[3 * nwc * 64 + dir] = Ic[u] + xb_;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (valid && (PM == 0 || (tblend && !(dir >= 1 && dir <= 8)))) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) {
+                        if (SP && t0 - u < 0) continue;
+                        const int so = (t0 - u) * RB;
+                        bstore(rIn, vo, so, v[u]);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
+                        if (SAVED) bstore(rS, vo, so, v[u]);
+                        if (SP && t0 - u == 0) {
+                            s_conv[2 * nwc * 64 + dir] = v[u];
+                            s_conv[3 * nwc * 64 + dir] = Ic[u] + v[u];
+                        }
+                    }
+                }
+            } else {
+                // general form (the ring kernel's; -DSOSRT_SCAN_GENERAL_SPECIAL builds only: the fast form covers every case)
+                double U = j == 0 ? Bv : wait_carry(NCH + j);
+#pragma unroll
+                for (int u = 0; u < TC; ++u) {
+                    const int t = t0 - u;
+                    const double Un = rec_step(U, Ec[u], cc[u]);
+                    double x = Un;
+                    if (w0 && t >= 0) x = blend(dir == 0 ? Jc[u] : Un);
+                    v[u] = x;
+                    const bool zone_start = t == zbeg1 || t == zbeg2;   // blended row feeds the zone above
+                    U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
+                    if (valid && t >= 0) {
+                        const int so = t * RB;
+                        bstore(rIn, vo, so, x);
+                        if (ACC) bstore(rI, vo, so, Ic[u] + x);
+                        if (SAVED) bstore(rS, vo, so, x);
+                    }
+                }
+                if (j + 1 < NCH) publish(NCH + j + 1, U);
+                if (t0 - TC < 0) {
+#pragma unroll
+                    for (int u = 0; u < TC; ++u)
+                        if (t0 - u == 0 && valid) {
+                            s_conv[2 * nwc * 64 + dir] = v[u];
+                            s_conv[3 * nwc * 64 + dir] = Ic[u] + v[u];
+                        }
+                }
+            }
+        };
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
+        using M3 = std::integral_constant<int, 3>;
+        // (the general form of the chunks with a zone boundary stays reachable: -DSOSRT_SCAN_GENERAL_SPECIAL builds)
+        for (int j = grp; j < NCH; j += SW) {
+            if ((sp_up >> j) & 1) {
+#ifdef SOSRT_SCAN_GENERAL_SPECIAL
+                chunk(std::true_type{}, M1{}, j);
+#else
+                if (!w0) chunk(std::true_type{}, M2{}, j);
+                else chunk(std::true_type{}, M3{}, j);
+#endif
+            }
+            else if (!w0) chunk(std::false_type{}, M0{}, j);
+            else chunk(std::false_type{}, M1{}, j);
+        }
+        if (w0 && notfound && lane == 0) s_flag[N - 3 <= 61 ? 1 : 0] = 1;
+    }
+    stamp(4);
+    __syncthreads();
+    stamp(5);
+    stamp(6);
+    stamp(7);
+    if (s_flag[2]) {                                                    // a carried value never arrived (internal error)
+        if (tid == 0) {
+            a.cv.status[b] = SOSRT_COL_INTERNAL;
+            if (ACC) { a.cv.active[b] = 0; a.cv.norders[b] = a.order; atomicSub(a.cv.nactive, 1); }
+        }
+        return;
+    }
+    if (s_flag[1]) {                                                    // the reference raises IndexError (spec:404)
+        if (tid == 0) {
+            a.cv.status[b] = SOSRT_COL_INDEXERROR;
+            if (ACC) { a.cv.active[b] = 0; a.cv.norders[b] = a.order; atomicSub(a.cv.nactive, 1); }
+        }
+        return;
+    }
+    // threads tid < N (the waves of chunk residue 0): direction tid
+    const bool act = tid < N;
+    double rup_v = act ? s_conv[2 * nwc * 64 + tid] : 0.0, rup_i = act ? s_conv[3 * nwc * 64 + tid] : 1.0;
+    const double rdn_v = act ? s_conv[0 * nwc * 64 + tid] : 0.0, rdn_i = act ? s_conv[1 * nwc * 64 + tid] : 1.0;
+    if (s_flag[0]) {
+        // A search of the upward sweep went past the lanes of the first lane group (spec:403-406 has no bound): redo that
+        // sweep here, row by row, the row exchanged through LDS so that every direction can be a candidate (as the ring
+        // kernel does; rare, written for size).  The rows stored above are read back past the L1 to correct the running
+        // total: I += new - old.
+        double* s_row = s_carry;                                        // [N] (free by now)
+        int& s_kf = *reinterpret_cast<int*>(s_red);
+        const int j = act ? tid : 0;
+        const bool tr = act && tid > 0;
+        const double mu = tr ? g.mu[N + j] : 1.0;
+        const double prmu = tr ? 1.0 / mu : 0.0;
+        const int vo = (N + j) * 8;
+        double U = Bv, Jnext = 0;                                       // (thread tid < N holds direction tid)
+        bool missing = false;
+        __syncthreads();
+        for (int t = L - 1; t >= 0; --t) {
+            double Un = 0, Jt = 0;
+            if (act) {
+                Jt = bload(rJ, vo, t * RB);
+                const double Et = bload(rE, vo, t * RB);
+                const double src = rec_src(rec_hr(s_hd[t + 1], prmu), Jnext, Et, Jt);
+                Un = rec_step(U, Et, (t == zend0 || t == zend1) ? 0.0 : src);      // first row of a zone: attenuate only (H4)
+                s_row[j] = tid == 0 ? Jt : Un;                                      // spec:401
+            }
+            if (tid == 0) s_kf = 1 << 30;
+            __syncthreads();
+            if (act && j >= 1 && j <= N - 3 && !(fabs((s_row[j] - s_row[j + 1]) - (s_row[j + 1] - s_row[j + 2])) > 0.0001))
+                atomicMin(&s_kf, j);
+            __syncthreads();
+            const int ks = s_kf;
+            missing |= ks == (1 << 30);
+            const int kf = ks == (1 << 30) ? 1 : ks + 1;
+            double x = act ? s_row[j] : 0.0;
+            if (tr && tid < kf) x = blend_val(blend_weight(mu, 1.0 / g.mu[N + kf]), s_row[0], s_row[kf]);
+            const bool zone_start = t == zbeg1 || t == zbeg2;           // blended row feeds the zone above (H5)
+            U = (zone_start && tr) ? x : Un;
+            Jnext = Jt;
+            if (act) {
+                const double x_old = bload_glc(rIn, vo, t * RB);
+                bstore(rIn, vo, t * RB, x);
+                double It = 0;
+                if (ACC) {
+                    It = bload_glc(rI, vo, t * RB) + (x - x_old);
+                    bstore(rI, vo, t * RB, It);
+                }
+                if (SAVED) bstore(rS, vo, t * RB, x);
+                if (t == 0) { rup_v = x; rup_i = It; }
+            }
+            __syncthreads();
+        }
+        if (missing) {                                                  // the reference raises IndexError (spec:404)
+            if (tid == 0) {
+                a.cv.status[b] = SOSRT_COL_INDEXERROR;
+                if (ACC) { a.cv.active[b] = 0; a.cv.norders[b] = a.order; atomicSub(a.cv.nactive, 1); }
+            }
+            return;
+        }
+    }
+    if (ACC) {
+        const double ra = block_pymax_(rup_v / rup_i, act, s_red, 0);
+        const double rb = block_pymax_(rdn_v / rdn_i, act, s_red, 0);
+        const double r = (rb > ra) ? rb : ra;                               // the outer max() of spec:309
+        if (tid == 0) {
+            a.cv.ratio[b] = r;
+            a.cv.norders[b] = a.order;
+            if (!(r >= a.cv.tol)) {
+                a.cv.active[b] = 0;
+                atomicSub(a.cv.nactive, 1);
+            }
+        }
+    } else if (tid == 0 && a.cv.status) {
+        a.cv.status[b] = SOSRT_COL_OK;
+    }
+}
+
+inline int scan_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
+inline size_t scan_lds_bytes(const Grid& g) {
+    const int nwc = (g.N + 63) / 64, ncw = nwc * SW, nwaves = ncw + SW;
+    const size_t doubles = (size_t)NST * STAGE + (size_t)nwc * CR * 64 + nwc * 64 + (size_t)kRingZones * scan_fixcap(g) * kFixMaxSrc + nwaves + 2 +
+                           g.L + 1 + (size_t)g.nsmall * g.L + 16 + 4 * nwc * 64 + (size_t)ncw * 2 * TC * 16;
+    return doubles * sizeof(double) + ((size_t)(nwc * CR + NST + NST * nwc) * sizeof(int) + 7) / 8 * 8;
+}
+
+}  // namespace
+
+// Half rows of one 1-KiB piece (N <= 128, N even: 16-byte lanes), at most 64 chunks per sweep (the mask of the chunks
+// with a zone boundary), stages and tables within the LDS of a CU.
+bool transport_scan_ok(const Grid& g) {
+    if (g.N % 2 || g.N < 4 || g.N > 128) return false;
+    if ((g.L + TC - 1) / TC > 64) return false;
+    return scan_lds_bytes(g) <= kScanLdsBytes;
+}
+
+void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a) {
+    const int nwc = (a.g.N + 63) / 64;
+    const dim3 block((nwc * SW + SW) * 64);
+    const size_t shm = scan_lds_bytes(a.g);
+#define SOSRT_SCAN_LAUNCH(ACC_, SAVED_)                                                                        \
+    do {                                                                                                       \
+        auto kern = k_transport_scan<ACC_, SAVED_>;                                                            \
+        static bool big_lds = false;                                                                           \
+        if (!big_lds) {                                                                                        \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)kScanLdsBytes);                                                           \
+            big_lds = true;                                                                                    \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
+    } while (0)
+    if (a.accumulate) {
+        if (a.saved) SOSRT_SCAN_LAUNCH(true, true);
+        else SOSRT_SCAN_LAUNCH(true, false);
+    } else {
+        SOSRT_SCAN_LAUNCH(false, false);
+    }
+#undef SOSRT_SCAN_LAUNCH
+}
+
+}  // namespace sosrt

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SOSRT_LIB") or os.path.join(os.path.dirname(_HERE), "libsosrt.so")
 
 SOSRT_OK, E_INVALID, E_HIP, E_STATE, E_NOMEM = 0, -1, -2, -3, -4
-COL_OK, COL_INDEXERROR, COL_MAXORDERS = 0, 1, 2
+COL_OK, COL_INDEXERROR, COL_MAXORDERS, COL_INTERNAL = 0, 1, 2, 3
 GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
 SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN, SURFACE_LAMBERTIAN_README = 0, 1, 2, 3
 K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU = 0, 1, 2, 3

@@ -68,6 +68,8 @@ def _raise_status(status, nb_angles):
     st = np.atleast_1d(status)
     if np.any(st == _lib.COL_INDEXERROR):
         raise IndexError("index %d is out of bounds for axis 1 with size %d" % (2 * nb_angles, 2 * nb_angles))
+    if np.any(st == _lib.COL_INTERNAL):
+        raise RuntimeError("sosrt: internal error in the transport kernel (SOSRT_COL_INTERNAL)")
 
 
 def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, alb_aer=1.0, z0=120, z_up=25, z_down=17,

@@ -16,7 +16,7 @@ from util import RTOL, assert_close, column_case, g1_case, golden, oracle_column
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fast", "ring", "general"])
+@pytest.fixture(params=["fast", "ring", "general", "scan"])
 def transport_mode(request, monkeypatch):
     """The transport kernels: the wave-independent one (+ repair), the same fed through an LDS ring by
     loader waves, and the general LDS-exchange one."""
