@@ -43,7 +43,7 @@ constexpr int CR = 8;                                      // ring of carried va
 constexpr int SROW = 128;                                  // doubles per staged row (one 1-KiB half row)
 constexpr int NST = 6;                                     // stages: chunk g (0 .. 2 NCH - 1 over the two sweeps) uses stage g mod NST
 constexpr int STAGE = (2 * TC + 1) * SROW;                 // doubles per stage: Jn, attenuation, + the Jn row before the chunk
-constexpr size_t kScanLdsBytes = 156 * 1024;
+constexpr size_t kScanLdsBytes = 152 * 1024;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value arrives within a few thousand polls)
 
@@ -73,13 +73,21 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     const int NCH = (L + TC - 1) / TC;
 
 #ifdef SOSRT_SCAN_STAMPS    // diagnostic builds: cycle stamps of the first and the last wave, [b][2][8] (tools/stamps_scan.py)
-    unsigned long long t_wait = 0, t_stage = 0;
-    auto stamp = [&](int i) __attribute__((always_inline)) {
+    unsigned long long t_wait = 0, t_stage = 0, t_pre = 0, t_post = 0, t_c = 0;
+    auto stamp = [&](int i) __attribute__((always_inline)) {     // [b][2][16]: 0-5 timeline, 6 carry wait, 7 stage wait, 8 pre-work, 9 post-work
         if (a.stamps && lane == 0 && (wid == 0 || wid == ncw - 1))
-            a.stamps[((size_t)b * 2 + (wid == 0 ? 0 : 1)) * 8 + i] = i == 6 ? t_wait : (i == 7 ? t_stage : clock64());
+            a.stamps[((size_t)b * 2 + (wid == 0 ? 0 : 1)) * 16 + i] = i == 6 ? t_wait : (i == 7 ? t_stage : (i == 8 ? t_pre : (i == 9 ? t_post : clock64())));
     };
+#define SCAN_T0() t_c = clock64()
+#define SCAN_T1() t_pre += clock64() - t_c
+#define SCAN_T2() t_c = clock64()
+#define SCAN_T3() t_post += clock64() - t_c
 #else
     auto stamp = [](int) {};
+#define SCAN_T0()
+#define SCAN_T1()
+#define SCAN_T2()
+#define SCAN_T3()
 #endif
     stamp(0);
     extern __shared__ double sm[];
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             const int t0 = q * TC;
             double Jc[TC], Ec[TC], Ic[TC], Jx_;
             take(q, vo, t0 * RB, RB, Jc, Ec, Ic, Jx_);
+            SCAN_T0();
             const double Jprev = q > 0 ? Jx_ : 0.0;
             // extrapolation table of the zone (In_limit:113-141 as a linear map): chunk-local copies
             double c[kFixMaxSrc] = {0, 0, 0, 0, 0};
@@ -329,8 +338,13 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         p = u == 0 ? Ec[0] : rec_hr(p, Ec[u]);
                         dl[u] = d; pl[u] = p;
                     }
+                    // (the chunk-local values exist before the wave starts polling: the compiler would otherwise sink their
+                    // computation below the wait, onto the serial path of the chain)
+                    asm volatile("" ::"v"(d), "v"(p));
                 }
+                SCAN_T1();
                 const double Din = q == 0 ? 0.0 : wait_carry(q);
+                SCAN_T2();
                 publish(q + 1, rec_step(Din, pl[TC - 1], dl[TC - 1]));      // on at once: the next chunk's wave waits for it
 #pragma unroll
                 for (int u = 0; u < TC; ++u) v[u] = rec_step(Din, pl[u], dl[u]);
@@ -382,7 +396,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                 // work items: the serial part is the recurrence alone -- the extrapolation is evaluated in line only for the
                 // row at a zone end, whose final value is the state of the next zone (spec:359,378) -- and the carried value
                 // leaves before the treatments and the stores.  Same operations per element as the general form below.
+                SCAN_T1();
                 double Dv = q == 0 ? 0.0 : wait_carry(q);
+                SCAN_T2();
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
                     const int t = t0 + u;
@@ -456,7 +472,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                 }
             } else {
                 // serial form (as the ring kernel): zone boundaries, last chunk
+                SCAN_T1();
                 double Dv = q == 0 ? 0.0 : wait_carry(q);
+                SCAN_T2();
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
                     const int t = t0 + u;
@@ -490,6 +508,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         }
                 }
             }
+            SCAN_T3();
         };
         using M0 = std::integral_constant<int, 0>;
         using M1 = std::integral_constant<int, 1>;
@@ -583,6 +602,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             const int t0 = L - 1 - j * TC;
             double Jc[TC], Ec[TC], Ic[TC], Jx_;
             take(NCH + j, vo, t0 * RB, -RB, Jc, Ec, Ic, Jx_);
+            SCAN_T0();
             const double Jnext = j > 0 ? Jx_ : 0.0;
             double cc[TC], v[TC];
 #pragma unroll
@@ -605,8 +625,11 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                             p = u == 0 ? Ec[0] : rec_hr(p, Ec[u]);
                             dl[u] = d; pl[u] = p;
                         }
+                        asm volatile("" ::"v"(d), "v"(p));      // (before the wave starts polling, as in the downward sweep)
                     }
+                SCAN_T1();
                     const double Uin = j == 0 ? Bv : wait_carry(NCH + j);
+                SCAN_T2();
                     publish(NCH + j + 1, rec_step(Uin, pl[TC - 1], dl[TC - 1]));      // on at once: the next chunk's wave waits for it
 #pragma unroll
                     for (int u = 0; u < TC; ++u) v[u] = rec_step(Uin, pl[u], dl[u]);
@@ -614,7 +637,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                     // fast form of a chunk with a zone boundary (or the last one): the serial part is the recurrence alone; the
                     // search and blend are evaluated in line only for the first row of a zone, whose blended value is the
                     // state of the zone above; the carried value leaves before the treatments and the stores
+                SCAN_T1();
                     double U = j == 0 ? Bv : wait_carry(NCH + j);
+                SCAN_T2();
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         const int t = t0 - u;
@@ -697,7 +722,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                 }
             } else {
                 // general form (the ring kernel's; -DSOSRT_SCAN_GENERAL_SPECIAL builds only: the fast form covers every case)
+                SCAN_T1();
                 double U = j == 0 ? Bv : wait_carry(NCH + j);
+                SCAN_T2();
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
                     const int t = t0 - u;
@@ -724,6 +751,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         }
                 }
             }
+            SCAN_T3();
         };
         using M0 = std::integral_constant<int, 0>;
         using M1 = std::integral_constant<int, 1>;
@@ -749,6 +777,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     stamp(5);
     stamp(6);
     stamp(7);
+    stamp(8);
+    stamp(9);
     if (s_flag[2]) {                                                    // a carried value never arrived (internal error)
         if (tid == 0) {
             a.cv.status[b] = SOSRT_COL_INTERNAL;

@@ -105,11 +105,26 @@ def small_mu_value(J, tau, zs, t, mu):
     return -acc / mu
 
 
-def transport_model(Jn, tau, mu, N, zones, nfix, surface, rho):
+TC = 8      # rows per chunk of the transport kernels
+
+
+def special_chunks(L, zones):
+    """Chunks (of TC rows, counted from the start of each sweep) that the chunk-parallel kernel evaluates in the serial
+    form: those with a zone boundary and the last one of the sweep.  Returns (set for the downward sweep, set for the upward)."""
+    nch = (L + TC - 1) // TC
+    rows = [r1 for (_, r1) in zones[:-1]] + [r0 for (r0, _) in zones[1:]]
+    return ({nch - 1} | {t // TC for t in rows}), ({nch - 1} | {(L - 1 - t) // TC for t in rows})
+
+
+def transport_model(Jn, tau, mu, N, zones, nfix, surface, rho, chunk_local=False):
     """zones: list of (r0, r1); nfix: rewritten-angle count per zone;
-    surface: None | 'specular' | 'lambertian'.  Returns (In, status)."""
+    surface: None | 'specular' | 'lambertian'.  Returns (In, status).
+    chunk_local: the arithmetic of transport_scan.hip -- inside a chunk without a zone boundary the recurrence
+    S_t = E_t S_{t-1} + c_t is evaluated as d_u = E_u d_{u-1} + c_u, p_u = E_u p_{u-1} from d = 0, p = 1 and
+    S_u = p_u S_in + d_u, with S_in the value carried out of the previous chunk."""
     L = len(tau)
     D = 2 * N
+    sp_dn, sp_up = special_chunks(L, zones) if chunk_local else (set(), set())
     In = np.zeros((L, D))
     tabs = [a4b_table(mu, N, k) for k in nfix]
     lane_small = np.abs(mu[:N]) < MU_THRESHOLD
@@ -125,10 +140,17 @@ def transport_model(Jn, tau, mu, N, zones, nfix, surface, rho):
         for t in range(L):
             zi = zone_of[t]
             r0, r1 = zones[zi]
-            if t > 0:
-                dl = tau[t] - tau[t - 1]
-                E = np.exp(dl / md)
-                Dv = Dv * E - (dl / 2) * (Jn[t - 1, :N] * E + Jn[t, :N]) / md
+            dl = tau[t] - tau[t - 1] if t > 0 else 0.0
+            E = np.exp(dl / md)
+            c = -(dl / 2) * (Jn[t - 1, :N] * E + Jn[t, :N]) / md if t > 0 else np.zeros(N)
+            if chunk_local and (t // TC) not in sp_dn:
+                if t % TC == 0:
+                    S_in, d_loc, p_loc = Dv.copy(), np.zeros(N), np.ones(N)
+                d_loc = d_loc * E + c
+                p_loc = p_loc * E
+                Dv = p_loc * S_in + d_loc
+            else:
+                Dv = Dv * E + c
             row = Dv.copy()
             row[N - 1] = 0.0
             for m in np.nonzero(lane_small)[0]:
@@ -161,13 +183,18 @@ def transport_model(Jn, tau, mu, N, zones, nfix, surface, rho):
         for t in range(L - 1, -1, -1):
             zi = zone_of[t]
             r0, r1 = zones[zi]
-            if t < L - 1:
-                dl = tau[t + 1] - tau[t]
-                E = np.exp(-dl / mp)
-                if t == r1:              # first row of a zone above: gap, no source integral
-                    U = U * E
-                else:
-                    U = U * E + (dl / 2) * (Jn[t, N:] + Jn[t + 1, N:] * E) / mp
+            dl = tau[t + 1] - tau[t] if t < L - 1 else 0.0
+            E = np.exp(-dl / mp)
+            # first row of a zone above: gap, no source integral
+            c = (dl / 2) * (Jn[t, N:] + Jn[t + 1, N:] * E) / mp if (t < L - 1 and t != r1) else np.zeros(N)
+            if chunk_local and ((L - 1 - t) // TC) not in sp_up:
+                if (L - 1 - t) % TC == 0:
+                    S_in, d_loc, p_loc = U.copy(), np.zeros(N), np.ones(N)
+                d_loc = d_loc * E + c
+                p_loc = p_loc * E
+                U = p_loc * S_in + d_loc
+            else:
+                U = U * E + c
             r = U.copy()
             r[0] = Jn[t, N]
             # blend

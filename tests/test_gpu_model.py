@@ -27,13 +27,16 @@ def test_single_slab(path):
         In, st = M.transport_model(d["Jn_%d" % n], tau, mu, N, [(0, L - 1)], [M.a4b_count(tS, N)], None, 0.0)
         assert st == 0
         assert_close(In, d["In_%d" % n], ALG, "In")
+        In, st = M.transport_model(d["Jn_%d" % n], tau, mu, N, [(0, L - 1)], [M.a4b_count(tS, N)], None, 0.0, chunk_local=True)
+        assert st == 0
+        assert_close(In, d["In_%d" % n], ALG, "In (chunk-local recurrences)")
         In_1 = d["In_%d" % n]
         n += 1
 
 
-@pytest.mark.parametrize("symmetric", [False, True], ids=["full", "symmetric"])
+@pytest.mark.parametrize("symmetric,chunk_local", [(False, False), (True, False), (True, True)], ids=["full", "symmetric", "symmetric+chunk-local"])
 @pytest.mark.parametrize("path", golden("g3_*.npz") + golden("g6_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
-def test_three_zone(path, symmetric):
+def test_three_zone(path, symmetric, chunk_local):
     d, c = column_case(path)
     N, L, mu, tau = c["N"], c["L"], c["mu"], c["tau"]
     iu, idn = c["idx_up"], c["idx_down"]
@@ -54,7 +57,8 @@ def test_three_zone(path, symmetric):
     while O.convergence_ratio(In, I, N) >= 1e-4:
         n += 1
         Jn = M.source_model(In_1, Wa, Wr, ca, cr, symmetric=symmetric)
-        In, st = M.transport_model(Jn, tau, mu, N, zones, nfix, c["surface"], c["grd_alb"])
+        # chunk_local: the recurrences in the chunk-local form of transport_scan.hip (a value carried per chunk of 8 rows)
+        In, st = M.transport_model(Jn, tau, mu, N, zones, nfix, c["surface"], c["grd_alb"], chunk_local=chunk_local)
         assert st == 0
         assert_close(In, Isv[n - 1], tol, "order %d" % n)
         In_1 = In
