@@ -39,7 +39,7 @@ def kernel_sources_sha():
     """Digest of the kernel sources the PMC traffic figures belong to."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("jn_gemm.hip", "transport_ring.hip", "kernels.hpp", "transport_util.hpp"):
+    for name in ("jn_gemm.hip", "transport_ring.hip", "transport_scan.hip", "kernels.hpp", "transport_util.hpp"):
         with open(os.path.join(ROOT, "sos-radiative-transfer_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -433,7 +433,7 @@ def main():
                   "matrix_asymmetry": asym,
                   "full_product_equivalent_tflops": full_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0}
         # HBM-bound: reads Jn, E, I and writes In, I = 40 L D bytes per column.order
-        r_tr = {"bound": "hbm", "kernel": "k_transport_ring", "achieved": tr_gbs, "peak": 8000.0, "unit": "GB/s",
+        r_tr = {"bound": "hbm", "kernel": "k_transport_ring + k_transport_scan", "achieved": tr_gbs, "peak": 8000.0, "unit": "GB/s",
                 "frac": tr_gbs / 8000.0, "traffic": None, "avg_launch_ms": tr_ms / max(tr_launches, 1),
                 "launches": tr_launches, "total_ms_per_step": tr_ms / a.steps}
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of the same workload (the counters cannot be
@@ -444,7 +444,7 @@ def main():
                 pmc = json.load(f)
             if B == 512 and L == 200 and N == 128 and world == 1 and pmc.get("kernel_sources_sha") == kernel_sources_sha():
                 r_gemm["traffic"] = pmc["k_jn_gemm"]["hbm_bytes_per_launch"]
-                r_tr["traffic"] = pmc["k_transport_ring"]["hbm_bytes_per_launch"]
+                r_tr["traffic"] = pmc["k_transport"]["hbm_bytes_per_launch"]
                 r_gemm["traffic_unit"] = r_tr["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/%s)" % PMC_FILE
         except (OSError, KeyError, ValueError):
             pass

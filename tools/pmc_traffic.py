@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def family(name):
-    for k in ("k_jn_gemm", "k_transport_ring", "k_transport_fast", "k_transport", "k_first_order", "k_attenuation", "k_smallmu", "k_epilogue",
+    for k in ("k_jn_gemm", "k_transport_ring", "k_transport_scan", "k_transport_fast", "k_transport", "k_first_order", "k_attenuation", "k_smallmu", "k_epilogue",
               "k_phase_p0", "k_prepare", "k_tau_hash", "k_tau_rep", "k_wmix", "k_finalize"):
         if k in name:
             return k
@@ -30,7 +30,7 @@ def collect(path, counter):
 
 def sha():
     h = hashlib.sha256()
-    for name in ("jn_gemm.hip", "transport_ring.hip", "kernels.hpp", "transport_util.hpp"):
+    for name in ("jn_gemm.hip", "transport_ring.hip", "transport_scan.hip", "kernels.hpp", "transport_util.hpp"):
         h.update(open(os.path.join(ROOT, "sos-radiative-transfer_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -44,6 +44,13 @@ for f in sorted(set(fetch) | set(write)):
     fb = 2.0 * 1024 * fetch.get(f, 0.0) / max(n, 1)
     wb = 1024 * write.get(f, 0.0) / max(n, 1)
     out[f] = {"launches_per_solve": n / solves, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+# the transport of a solve: the ring kernel for the first orders, the chunk-parallel kernel from order SOSRT_SCAN_FROM on
+tr = [out[k] for k in ("k_transport_ring", "k_transport_scan") if k in out]
+if tr:
+    n = sum(x["launches_per_solve"] for x in tr)
+    out["k_transport"] = {"launches_per_solve": n}
+    for key in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch"):
+        out["k_transport"][key] = sum(x[key] * x["launches_per_solve"] for x in tr) / n
 out["kernel_sources_sha"] = sha()
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/run_once.py 512 %d "
                 "(solves of the bench sweep); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streams; counter "
