@@ -7,7 +7,7 @@ import sos_oracle as O
 from sosrt import _lib, inputs
 from sosrt.main import SOS_Aer_batch
 from sosrt.solver import Solver
-from util import RTOL, assert_close
+from util import RTOL, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -296,6 +296,45 @@ def test_two_column_groups_on_two_streams_are_bit_identical(monkeypatch):
     assert (a.status == 0).all()
     assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
     assert np.array_equal(a.I, b.I)                         # bit for bit
+
+
+def test_transport_kernel_by_order_index_keeps_batch_invariance(monkeypatch):
+    """Default mode: the ring kernel below order SOSRT_SCAN_FROM, the chunk-parallel kernel (chunk-local recurrences: other
+    rounding) from there on.  The switch is by the order index, so (1) a column solved alone, in a sub-batch or in the
+    whole batch has the same bits, with the switch in the middle of the solves (SCAN_FROM = 6) as with the default; (2)
+    against the ring kernel for every order the fields move by rounding only and the order counts not at all."""
+    from sosrt import main as M
+    rng = np.random.default_rng(23)
+    B = 40
+    mu0 = rng.uniform(0.2, 1.0, B)
+    taer = rng.choice([0.02, 0.12, 0.6], B)
+    rho = rng.uniform(0.0, 0.8, B)
+    kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=72, nb_angles=64, max_orders=200)
+
+    def fresh(**env):
+        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_FROM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+
+    fresh(SOSRT_TRANSPORT="ring")
+    ring = SOS_Aer_batch(mu0, taer, rho, **kw)
+    assert (ring.status == 0).all() and ring.n.max() >= 14 and ring.n.min() < 14
+    for scan_from in ("6", None):
+        fresh(**({"SOSRT_SCAN_FROM": scan_from} if scan_from else {}))
+        whole = SOS_Aer_batch(mu0, taer, rho, **kw)
+        assert np.array_equal(whole.n, ring.n) and (whole.status == 0).all()
+        assert rel_err(whole.I, ring.I) <= 1e-12
+        assert not np.array_equal(whole.I, ring.I)              # (the chunk-parallel kernel did run)
+        sub = SOS_Aer_batch(mu0[7:19], taer[7:19], rho[7:19], **kw)
+        assert np.array_equal(sub.I, whole.I[7:19])             # bit for bit
+        slow = int(np.argmax(ring.n))
+        one = SOS_Aer_batch(mu0[slow:slow + 1], taer[slow:slow + 1], rho[slow:slow + 1], **kw)
+        assert np.array_equal(one.I[0], whole.I[slow]) and one.n[0] == whole.n[slow]
+    fresh()
 
 
 def test_reference_shipped_size_L800_N501():
