@@ -24,7 +24,7 @@ def test_bench_single_gpu_line():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["unit"] == "columns/s" and d["value"] > 0 and d["dtype"] == "f64"
     assert d["roofline"]["bound"] in ("mfma", "hbm") and 0 < d["roofline"]["frac"] < 1
-    assert {d["roofline"]["kernel"], d["roofline_other"]["kernel"]} == {"k_jn_gemm", "k_transport_ring"}
+    assert {d["roofline"]["kernel"], d["roofline_other"]["kernel"]} == {"k_jn_gemm", "k_transport_ring + k_transport_scan"}
     assert d["config"]["not_converged"] == 0 and d["config"]["columns_per_gpu"] == 64
     # the run checks itself: sampled columns against the oracle, outside the timed region
     assert d["check"]["ok"] and d["check"]["max_rel_err_vs_oracle"] <= 1e-10 and d["check"]["orders_match"]
