@@ -337,6 +337,35 @@ def test_transport_kernel_by_order_index_keeps_batch_invariance(monkeypatch):
     fresh()
 
 
+@pytest.mark.parametrize("L,N", [(3, 8), (4, 64), (5, 128), (8, 32), (9, 128), (17, 100), (33, 64), (65, 128)])
+def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
+    """The chunk-parallel kernel for every order on columns of fewer chunks than it has waves, ragged last chunks, one or
+    two lane groups, against the ring kernel: same order counts and statuses (IndexError, order budget), fields equal to
+    rounding (identical where every chunk has a zone boundary)."""
+    from sosrt import main as M
+    rng = np.random.default_rng(100 * L + N)
+    B = 5
+    mu0 = rng.uniform(0.2, 1.0, B)
+    taer = rng.choice([0.02, 0.12, 0.6], B)
+    rho = rng.uniform(0.0, 0.8, B)
+    kw = dict(tauStar_atm=0.124, alb_aer=0.9, nb_layers=L, nb_angles=N, max_orders=120, raise_on_error=False, z_up=80, z_down=40)
+    out = {}
+    for mode in ("ring", "scan"):
+        monkeypatch.setenv("SOSRT_TRANSPORT", mode)
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+        out[mode] = SOS_Aer_batch(mu0, taer, rho, **kw)
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    a, b = out["ring"], out["scan"]
+    assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
+    live = a.status == 0
+    if live.any():
+        assert rel_err(b.I[live], a.I[live]) <= 1e-12
+
+
 def test_reference_shipped_size_L800_N501():
     """The size the reference ships (spec:33,57: nb_layers = 800, nb_angles = 501 -- odd and > 256, so the
     register-streaming transport kernel and the N >= 501 extrapolation tables) against the oracle, one column, at
