@@ -64,7 +64,10 @@ int sosrt_version(void);
  * (plan queries only, no GPU is touched). */
 int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_t** out);
 int sosrt_destroy(sosrt_t* h);
-/* run on a caller-provided hipStream_t (e.g. the current torch stream); NULL = the handle's own */
+/* run on a caller-provided hipStream_t (e.g. the current torch stream); NULL = the handle's own stream.  The own stream is
+ * non-blocking: it does NOT synchronise with the legacy default stream, and the default stream's handle IS NULL -- a
+ * caller that enqueues work on the default stream (torch without an explicit stream) either passes an explicit stream
+ * here or synchronises before and after the calls. */
 int sosrt_set_stream(sosrt_t* h, void* hip_stream);
 int sosrt_synchronize(sosrt_t* h);
 /* I_saved_out of the solves that follow holds `slots` orders per column ([B][slots][L][2N], 1 <= slots <=

@@ -134,7 +134,11 @@ struct sosrt_handle {
     // for every order.  The choice depends on the order index only, never on the live columns of the batch.
     int transport_mode = 3;
     int scan_from = 14;                  // SOSRT_SCAN_FROM: first order of the chunk-parallel kernel in mode 3
-    bool ring_ok = false, scan_ok = false;
+    bool ring_ok = false, scan_ok = false, scan_split_ok = false;
+    int scan_split = 1;                  // SOSRT_SCAN_SPLIT: two workgroups per column when at most half as many columns are live as the device has CUs
+    int cu_count = 0;
+    double* d_scan_scratch = nullptr;    // [max_batch][transport_scan_scratch_doubles()] exchange rows of the split form
+    int* d_scan_sync = nullptr;          // [max_batch][2] {arrivals, flags}, zero between launches
     int gemm_tail_cols = 1 << 30;        // at or below this many live columns (and below the batch) tiles are laid over live columns (SOSRT_GEMM_TAIL)
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
     bool fast_ok = false;
@@ -408,6 +412,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
         h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : (strcmp(ev, "scan") == 0 ? 4 : (strcmp(ev, "auto") == 0 ? 3 : 1)));
     if (const char* ev = getenv("SOSRT_SCAN_FROM")) h->scan_from = atoi(ev);
+    if (const char* ev = getenv("SOSRT_SCAN_SPLIT")) h->scan_split = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
@@ -485,6 +490,10 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_mixcr, sosrt_handle::kMaxMixGroups))) return e;
             if ((e = dalloc(&h->d_tauhash, mb))) return e;
             if ((e = dalloc(&h->d_ratio, mb))) return e;
+            if ((e = dalloc(&h->d_scan_scratch, mb * transport_scan_scratch_doubles()))) return e;
+            if ((e = dalloc(&h->d_scan_sync, 2 * mb))) return e;
+            HIPCHK(hipMemset(h->d_scan_sync, 0, 2 * mb * sizeof(int)));
+            HIPCHK(hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, device));
             // + 2 ints at the end: {needs k_smallmu, tag} published at the start of a solve
             HIPCHK(hipHostMalloc((void**)&h->h_pub, (8 * sosrt_handle::kMaxGroups + 2) * sizeof(int), hipHostMallocCoherent));
             memset(h->h_pub, 0, (8 * sosrt_handle::kMaxGroups + 2) * sizeof(int));
@@ -514,7 +523,7 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr};
+                        h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_scan_scratch, h->d_scan_sync, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -623,6 +632,7 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
             HIPCHK(hipMemcpy(h->d_small, h->plan.small_lanes.data(), h->g.nsmall * sizeof(int), hipMemcpyHostToDevice));
         h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
         h->scan_ok = h->ring_ok && transport_scan_ok(h->g);
+        h->scan_split_ok = h->scan_ok && transport_scan_split_ok(h->g);
     }
     return 0;
 }
@@ -1107,8 +1117,14 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 const int fast_mode = (h->scan_ok && (h->transport_mode == 4 || (h->transport_mode == 3 && n >= h->scan_from))) ? 4 : ring_mode;
                 Grid gt = g;
                 if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
+                // chunk-parallel kernel: a column on two CUs while at most half as many columns are live as there are CUs (same
+                // arithmetic per direction, so the choice may follow the live count; the reflection must stay inside a half)
+                const int cols_now = tail_cols > 0 ? tail_cols : q.nb;
+                const int split = (fast_mode == 4 && h->scan_split && h->scan_split_ok && 2 * cols_now <= h->cu_count &&
+                                   (h->surface == SOSRT_SURFACE_SPECULAR || h->surface == SOSRT_SURFACE_NONE)) ? 1 : 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
-                                 h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0);
+                                 h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0, split,
+                                 h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(), h->d_scan_sync + 2 * q.b0);
                 if (h->N - 3 > 61 && fast_mode == 1)     // register-streaming kernel: a search that leaves wave 0 is redone by the
                     launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                      h->d_E, 2, erep_g);         // general kernel (flag cv.redo); the ring kernel redoes it itself

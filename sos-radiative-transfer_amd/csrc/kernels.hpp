@@ -118,6 +118,10 @@ struct TransportArgs {
     int live = 0;
     const int* live_list = nullptr;
     int slots = 0;             // ring depth of this launch (0: the default)
+    // chunk-parallel kernel, two workgroups per column (transport_scan.hip): exchange rows and {arrivals, flags} per column
+    int scan_split = 0;
+    double* scan_scratch = nullptr;
+    int* scan_sync = nullptr;
 };
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
@@ -125,6 +129,8 @@ bool transport_ring_ok(const Grid& g);
 void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots);
 // transport_scan.hip: the chunks of a sweep dealt to several waves (chunk-local recurrence + carried values)
 bool transport_scan_ok(const Grid& g);
+bool transport_scan_split_ok(const Grid& g);
+size_t transport_scan_scratch_doubles();                       // per column
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a);
 extern int g_ring_slots, g_ring_debug;                        // tuning (SOSRT_RING_SLOTS)
 extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
@@ -203,7 +209,7 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
                       const double* Etab, int mode, const int* erep = nullptr, int live = 0, const int* live_list = nullptr,
-                      int ring_slots = 0);
+                      int ring_slots = 0, int scan_split = 0, double* scan_scratch = nullptr, int* scan_sync = nullptr);
 bool transport_fast_ok(const Plan& plan);
 // erep (nullable): tables are built only for columns with erep[b] == b
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep);

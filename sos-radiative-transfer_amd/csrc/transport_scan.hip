@@ -38,20 +38,32 @@ namespace sosrt {
 
 namespace {
 
-constexpr int SW = 4;                                      // waves per lane group = chunks of a sweep in flight
-constexpr int CR = 8;                                      // ring of carried values per lane group (> SW)
-constexpr int SROW = 128;                                  // doubles per staged row (one 1-KiB half row)
-constexpr int NST = 6;                                     // stages: chunk g (0 .. 2 NCH - 1 over the two sweeps) uses stage g mod NST
-constexpr int STAGE = (2 * TC + 1) * SROW;                 // doubles per stage: Jn, attenuation, + the Jn row before the chunk
+// One workgroup per column: 2 lane groups x 4 chunk residues.  SPLIT (two workgroups per column, chosen for launches with
+// few live columns: a lone column is bound by the memory path of the one CU it lives on): a workgroup takes HALF the
+// directions -- part 0 the |mu| < mu_mid half of both sweeps (upward directions N .. N+63 and their mirror images, the
+// downward directions N-64 .. N-1: every mu -> 0 treatment), part 1 the rest -- so that the specular reflection, which maps a
+// downward direction onto its mirror image, stays inside a workgroup, and no workgroup ever waits for another; one lane
+// group x 8 chunk residues.  The arithmetic per direction is the same, so the choice is free (it follows the live count).
+template <bool SPLIT> struct ScanCfg {
+    static constexpr int SW = SPLIT ? 8 : 4;               // waves per lane group = chunks of a sweep in flight
+    static constexpr int NST = SPLIT ? 12 : 6;             // stages: chunk g (0 .. 2 NCH - 1 over the two sweeps) uses stage g mod NST
+    static constexpr int SROW = SPLIT ? 64 : 128;          // doubles per staged row (half a 1-KiB half row when split)
+    static constexpr int STAGE = (2 * TC + 1) * SROW;      // doubles per stage: Jn, attenuation, + the Jn row before the chunk
+};
+constexpr int NLOAD = 4;                                   // loader waves
+constexpr int CR = 16;                                     // ring of carried values per lane group (> SW)
+constexpr int kScanScratch = 5 * 128;                      // doubles per column of the split form's exchange: 4 test rows + surface row
 constexpr size_t kScanLdsBytes = 152 * 1024;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value arrives within a few thousand polls)
 
-template <bool ACC, bool SAVED>
+template <bool ACC, bool SAVED, bool SPLIT>
 __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fixcap) {
-    int b = blockIdx.x;
+    constexpr int SW = ScanCfg<SPLIT>::SW, NST = ScanCfg<SPLIT>::NST, SROW = ScanCfg<SPLIT>::SROW, STAGE = ScanCfg<SPLIT>::STAGE;
+    const int part = SPLIT ? (int)(blockIdx.x & 1) : 0;
+    int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
     if (ACC && a.live > 0) {
-        b = a.live_list[blockIdx.x];
+        b = a.live_list[b];
         if (b < 0) return;                          // fewer live columns than the host's (lagging) count
     } else if (ACC && !a.cv.active[b]) {
         return;
@@ -60,22 +72,29 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int L = g.L, N = g.N, D = g.D;
-    const int nwc = (N + 63) >> 6;                             // lane groups
-    const int ncw = nwc * SW;                                  // computing waves; the SW loader waves follow
+    const int nwc = SPLIT ? 1 : (N + 63) >> 6;                 // lane groups of this workgroup
+    const int ND = ((N + 63) >> 6) * 64;                       // stride of the per-direction LDS rows
+    const int ncw = nwc * SW;                                  // computing waves; the NLOAD loader waves follow
     const bool loader = wid >= ncw;
-    const int lg = wid % nwc, grp = loader ? wid - ncw : wid / nwc;   // this wave: 64 directions, chunks grp, grp + SW, ...
-    const int dir = lg * 64 + lane;                            // downward direction dir, then upward direction N + dir
+    const int lg = wid % nwc, grp = loader ? wid - ncw : wid / nwc;   // this wave: 64 directions, chunks grp, grp + SW, ... (loaders: grp, grp + NLOAD, ...)
+    // downward direction dir_dn, then upward direction N + dir; split: part 0 = upward 0..63 and their mirror images N-64..N-1
+    const int dir = SPLIT ? part * 64 + lane : lg * 64 + lane;
+    const int dir_dn = SPLIT ? (part == 0 ? N - 64 + lane : lane) : dir;
     const bool valid = dir < N;
+    const bool valid_dn = SPLIT ? (part == 0 || lane < N - 64) : valid;
     const int dirc = valid ? dir : N - 1;
-    const bool w0 = !loader && lg == 0;                        // holds the mu -> 0+ lanes
-    const bool wl = !loader && lg == ((N - 1) >> 6);           // holds the mu -> 0- lanes
+    const int dirc_dn = valid_dn ? dir_dn : 0;
+    const bool w0 = !loader && (SPLIT ? part == 0 : lg == 0);                    // holds the mu -> 0+ lanes
+    const bool wl = !loader && (SPLIT ? part == 0 : lg == ((N - 1) >> 6));       // holds the mu -> 0- lanes
+    const int lane_last = SPLIT ? 63 : ((N - 1) & 63);         // lane of downward direction N-1 in the wave that holds it
+    const int dn_base = SPLIT ? N - 64 : (((N - 1) >> 6) << 6);  // downward direction of lane 0 of that wave
     const int nwaves = blockDim.x >> 6;
     const int NCH = (L + TC - 1) / TC;
 
 #ifdef SOSRT_SCAN_STAMPS    // diagnostic builds: cycle stamps of the first and the last wave, [b][2][8] (tools/stamps_scan.py)
     unsigned long long t_wait = 0, t_stage = 0, t_pre = 0, t_post = 0, t_c = 0;
     auto stamp = [&](int i) __attribute__((always_inline)) {     // [b][2][16]: 0-5 timeline, 6 carry wait, 7 stage wait, 8 pre-work, 9 post-work
-        if (a.stamps && lane == 0 && (wid == 0 || wid == ncw - 1))
+        if (a.stamps && lane == 0 && part == 0 && (wid == 0 || wid == ncw - 1))
             a.stamps[((size_t)b * 2 + (wid == 0 ? 0 : 1)) * 16 + i] = i == 6 ? t_wait : (i == 7 ? t_stage : (i == 8 ? t_pre : (i == 9 ? t_post : clock64())));
     };
 #define SCAN_T0() t_c = clock64()
@@ -93,14 +112,14 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     extern __shared__ double sm[];
     double* s_stage = sm;                                      // [NST][STAGE] rows of the chunks in flight
     double* s_carry = s_stage + (size_t)NST * STAGE;            // [nwc][CR][64] ring of the values carried into the chunks
-    double* s_sfc = s_carry + (size_t)nwc * CR * 64;           // [nwc * 64] surface row by downward direction
-    double* s_fixc = s_sfc + nwc * 64;                         // [kRingZones][fixcap][kFixMaxSrc] compact extrapolation tables
+    double* s_sfc = s_carry + (size_t)nwc * CR * 64;           // [ND] surface row by downward direction
+    double* s_fixc = s_sfc + ND;                         // [kRingZones][fixcap][kFixMaxSrc] compact extrapolation tables
     double* s_red = s_fixc + kRingZones * fixcap * kFixMaxSrc; // [nwaves + 2]
     double* s_hd = s_red + nwaves + 2;                         // [L + 1] half layer thicknesses
     double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
     double* s_prmu = s_S + (size_t)g.nsmall * L;               // [16] 1/mu of the first upward directions
-    double* s_conv = s_prmu + 16;                              // [4][nwc * 64] last rows of the sweeps: value, running total
-    double* s_xw = s_conv + 4 * nwc * 64;                      // [ncw][2][TC * 16] per-wave exchange: values, running totals
+    double* s_conv = s_prmu + 16;                              // [4][ND] last rows of the sweeps: value, running total
+    double* s_xw = s_conv + 4 * ND;                      // [ncw][2][TC * 16] per-wave exchange: values, running totals
     // flags (ints): [nwc][CR] sequence number of the carried value in a slot, [NST] chunk landed in a stage,
     // [NST][nwc] chunk taken out of a stage by a lane group (chunk numbers g + 1)
     int* s_flagq = reinterpret_cast<int*>(s_xw + (size_t)ncw * 2 * TC * 16);
@@ -109,7 +128,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     __shared__ int s_flag[3];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] internal
     double* s_x = s_xw + (size_t)(loader ? 0 : wid) * 2 * TC * 16;
     double* s_xI = s_x + TC * 16;
-    const int xb_dn = max(((N - 1) & 63) - 15, 0);
+    const int xb_dn = max(lane_last - 15, 0);
 
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
@@ -204,7 +223,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         t_stage += t_wait - tw_; t_wait = tw_;
 #endif
         typedef __attribute__((address_space(3))) double lds_double;
-        const lds_double* st = (const lds_double*)(s_stage + (size_t)stg * STAGE + dirc);
+        // (a staged row holds the whole half row by direction, or -- split -- this workgroup's 64 directions by lane)
+        const lds_double* st = (const lds_double*)(s_stage + (size_t)stg * STAGE + (SPLIT ? lane : (gq < NCH ? dirc_dn : dirc)));
         asm volatile("" ::: "memory");                      // (compiler only: the reads stay between the two flag accesses)
 #pragma unroll
         for (int u = 0; u < TC; ++u) {
@@ -224,23 +244,26 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         const int q = up ? gq - NCH : gq;
         double* dst = s_stage + (size_t)(gq % NST) * STAGE;
         const int t0 = up ? L - 1 - q * TC : q * TC;
-        const int half = up ? N * 8 : 0;
+        // byte offset of this workgroup's directions in a row: the half row (1 KiB pieces), or -- split -- its 64 directions (512 B)
+        const int half = SPLIT ? (up ? N * 8 + part * 512 : (part == 0 ? (N - 64) * 8 : 0)) : (up ? N * 8 : 0);
         const int vo = lane * 16;
+        if (!SPLIT || lane < 32) {
 #pragma unroll
-        for (int u = 0; u < TC; ++u) {
-            const int row = up ? max(t0 - u, 0) : min(t0 + u, L - 1);
-            const int so = row * RB + half;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROW), 16, vo, so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROW), 16, vo, so, 0, 0);
+            for (int u = 0; u < TC; ++u) {
+                const int row = up ? max(t0 - u, 0) : min(t0 + u, L - 1);
+                const int so = row * RB + half;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROW), 16, vo, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROW), 16, vo, so, 0, 0);
+            }
+            const int rx = up ? min(t0 + 1, L - 1) : max(t0 - 1, 0);     // the row before the chunk (unused by the first chunk)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROW), 16, vo, rx * RB + half, 0, 0);
         }
-        const int rx = up ? min(t0 + 1, L - 1) : max(t0 - 1, 0);     // the row before the chunk (unused by the first chunk)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROW), 16, vo, rx * RB + half, 0, 0);
     };
     // Loader `grp` carries the chunks g = grp, grp + SW, ... of both sweeps.  Chunk g goes into stage g mod NST once every
     // lane group has taken chunk g - NST out of it: with NST > SW a residue's next chunk is requested before its current
     // one is even started.
     auto load_chunks = [&](int g0, int g1) __attribute__((always_inline)) {
-        for (int gq = g0; gq < g1; gq += SW) {
+        for (int gq = g0; gq < g1; gq += NLOAD) {
             if (gq >= NST)
                 for (int i = 0; i < nwc; ++i) spin(l_taken + (gq % NST) * nwc + i, gq - NST + 1);
             issue(gq);
@@ -263,10 +286,11 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     if (loader) {
         // the chunks of the downward sweep and, across the seam, the first ones of the upward sweep
         load_chunks(g_next, g_seam);
-        while (g_next < g_seam) g_next += SW;
+        while (g_next < g_seam) g_next += NLOAD;
     } else {
-        const int m = dirc;
+        const int m = dirc_dn;
         const int vo = m * 8;
+        const bool valid = valid_dn;                        // (of the downward direction, in this block)
         const double mu = g.mu[m];
         const bool tr = valid && m <= N - 2;
         const bool small = tr && fabs(mu) < kMuThreshold;       // spec:333
@@ -274,7 +298,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         const double nrmu = stdl ? -1.0 / mu : 0.0;
         const bool has_small = wl && g.nsmall > 0;
         const int sbase = small ? (m - g.small_lanes[0]) * L : 0;   // the small lanes are consecutive directions
-        const int lmT = ((N - 1) & 63) - pT;                        // lane of direction N-1-pT in the wave that holds it
+        const int lmT = lane_last - pT;                        // lane of direction N-1-pT in the wave that holds it
         auto zone_of = [&](int t) __attribute__((always_inline)) { return (zbeg2 >= 0 && t >= zbeg2) ? 2 : ((zbeg1 >= 0 && t >= zbeg1) ? 1 : 0); };
         // (by shifts: a chain of selects over the three captured counts becomes a table of pointers on the stack, read back
         // with FLAT loads that wait for every global load and store in flight)
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                 for (int k = 0; k < kFixMaxSrc; ++k) {
                     if (SP || MODE == 2) c[k] = (fixlane && k < ns) ? ftC[i * ns + min(k, ns - 1)] : 0.0;     // (incl. the fast special form)
                     if (!SP) cT[k] = (pT < nfx && k < ns) ? ftC[pT * ns + min(k, ns - 1)] : 0.0;
-                    sl[k] = (s0 + min(k, ns - 1)) & 63;
+                    sl[k] = s0 + min(k, ns - 1) - dn_base;            // lane of the source direction
                 }
             };
             if (wl && ((SP && MODE != 3) || (!SP && MODE != 0))) load_fix(zone_of(t0));
@@ -436,7 +460,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 #pragma unroll
                     for (int k = 0; k < kFixMaxSrc; ++k) {
                         const double ck = (pT < nfT && k < nsT) ? ftT[pT * nsT + min(k, nsT - 1)] : 0.0;
-                        const int sk = ((s0T + min(k, nsT - 1)) & 63) - xb_dn;
+                        const int sk = s0T + min(k, nsT - 1) - dn_base - xb_dn;
                         acc = fix_acc(ck, xrow[max(sk, 0)], acc);
                     }
                     const int mT = N - 1 - pT;
@@ -448,8 +472,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         if (SAVED) bstore(rS, voT, 0, acc);
                         if (tT == L - 1) {
                             s_sfc[mT] = acc;
-                            s_conv[0 * nwc * 64 + mT] = acc;
-                            s_conv[1 * nwc * 64 + mT] = IcT + acc;
+                            s_conv[0 * ND + mT] = acc;
+                            s_conv[1 * ND + mT] = IcT + acc;
                         }
                     }
                 }
@@ -464,9 +488,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
                         if (SAVED) bstore(rS, vo, so, v[u]);
                         if (t == L - 1) {
-                            s_sfc[dir] = v[u];
-                            s_conv[0 * nwc * 64 + dir] = v[u];
-                            s_conv[1 * nwc * 64 + dir] = Ic[u] + v[u];
+                            s_sfc[dir_dn] = v[u];
+                            s_conv[0 * ND + dir_dn] = v[u];
+                            s_conv[1 * ND + dir_dn] = Ic[u] + v[u];
                         }
                     }
                 }
@@ -502,9 +526,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 #pragma unroll
                     for (int u = 0; u < TC; ++u)
                         if (t0 + u == L - 1 && valid) {
-                            s_sfc[dir] = v[u];
-                            s_conv[0 * nwc * 64 + dir] = v[u];
-                            s_conv[1 * nwc * 64 + dir] = Ic[u] + v[u];
+                            s_sfc[dir_dn] = v[u];
+                            s_conv[0 * ND + dir_dn] = v[u];
+                            s_conv[1 * ND + dir_dn] = Ic[u] + v[u];
                         }
                 }
             }
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                     for (int zz = za; zz <= zb; ++zz) {
                         const int nf = nfix_of(zz);
                         const int ns = nf < 2 ? 2 : (nf < kFixMaxSrc ? nf : kFixMaxSrc);
-                        const int sl0 = (nf < 2 ? N - nf - 2 : N - nf - ns) & 63;
+                        const int sl0 = (nf < 2 ? N - nf - 2 : N - nf - ns) - dn_base;
                         fastsp = fastsp && nf <= 8 && (nf == 0 || sl0 >= xb_dn);
                     }
                 }
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                 // MODE: 0 this wave has no treated lane here, 1 the transposed extrapolation alone, 2 anything else
                 const int nfx = nfix_of(zone_of(q * TC));
                 const int ns = nfx < 2 ? 2 : (nfx < kFixMaxSrc ? nfx : kFixMaxSrc);
-                const int sl0 = (nfx < 2 ? N - nfx - 2 : N - nfx - ns) & 63;
+                const int sl0 = (nfx < 2 ? N - nfx - 2 : N - nfx - ns) - dn_base;
                 const int mode = (!wl || (nfx == 0 && !has_small)) ? 0 : ((!has_small && nfx <= 8 && sl0 >= xb_dn) ? 1 : 2);
                 if (mode == 0) chunk(std::false_type{}, M0{}, q);
                 else if (mode == 1) chunk(std::false_type{}, M1{}, q);
@@ -685,8 +709,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                             if (ACC) bstore(rI, voT, 0, IcT + val);
                             if (SAVED) bstore(rS, voT, 0, val);
                             if (SP && t0 - uT == 0) {
-                                s_conv[2 * nwc * 64 + k] = val;
-                                s_conv[3 * nwc * 64 + k] = IcT + val;
+                                s_conv[2 * ND + k] = val;
+                                s_conv[3 * ND + k] = IcT + val;
                             }
                         }
                     } else {
@@ -699,8 +723,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                                 if (ACC) bstore(rI, vo, so, Ic[u] + xb_);
                                 if (SAVED) bstore(rS, vo, so, xb_);
                                 if (SP && t0 - u == 0) {
-                                    s_conv[2 * nwc * 64 + dir] = xb_;
-                                    s_conv[3 * nwc * 64 + dir] = Ic[u] + xb_;
+                                    s_conv[2 * ND + dir] = xb_;
+                                    s_conv[3 * ND + dir] = Ic[u] + xb_;
                                 }
                             }
                         }
@@ -715,8 +739,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
                         if (SAVED) bstore(rS, vo, so, v[u]);
                         if (SP && t0 - u == 0) {
-                            s_conv[2 * nwc * 64 + dir] = v[u];
-                            s_conv[3 * nwc * 64 + dir] = Ic[u] + v[u];
+                            s_conv[2 * ND + dir] = v[u];
+                            s_conv[3 * ND + dir] = Ic[u] + v[u];
                         }
                     }
                 }
@@ -746,8 +770,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 #pragma unroll
                     for (int u = 0; u < TC; ++u)
                         if (t0 - u == 0 && valid) {
-                            s_conv[2 * nwc * 64 + dir] = v[u];
-                            s_conv[3 * nwc * 64 + dir] = Ic[u] + v[u];
+                            s_conv[2 * ND + dir] = v[u];
+                            s_conv[3 * ND + dir] = Ic[u] + v[u];
                         }
                 }
             }
@@ -779,6 +803,49 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     stamp(7);
     stamp(8);
     stamp(9);
+    if (SPLIT) {
+        // The two workgroups of the column meet here without waiting: each leaves its test rows, its surface row and its
+        // flags in global memory, and the one that arrives second runs the rest for the whole column.  The few exchanged
+        // words go as device-scope atomics (performed at the coherence point: the workgroups may sit on different XCDs, whose
+        // L2s are not coherent), acknowledged before the arrival counter moves -- no release / acquire fence, which would
+        // write back and invalidate a whole L2 under the other columns' feet.  Only a workgroup that asks for the row-by-row
+        // redo, which reads the other half's field rows, pays for the fence.
+        double* gs = a.scan_scratch + (size_t)b * kScanScratch;            // [4 test rows + surface row][128]
+        int* sync = a.scan_sync + 2 * b;                                   // {arrivals, flags}
+        __shared__ int s_last;
+        if (wid == 0) {                                                    // (lanes = this workgroup's directions)
+            if (valid_dn) {
+                __hip_atomic_store(gs + 0 * 128 + dir_dn, s_conv[0 * ND + dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 1 * 128 + dir_dn, s_conv[1 * ND + dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 4 * 128 + dir_dn, s_sfc[dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (valid) {
+                __hip_atomic_store(gs + 2 * 128 + dir, s_conv[2 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 3 * 128 + dir, s_conv[3 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int f = (s_flag[0] ? 1 : 0) | (s_flag[1] ? 2 : 0) | (s_flag[2] ? 4 : 0);
+            if (f && lane == 0) __hip_atomic_fetch_or(sync + 1, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // acknowledged: the words are where the other workgroup reads them
+        }
+        if (s_flag[0]) __atomic_thread_fence(__ATOMIC_RELEASE);           // (uniform) the redo will read this half's field rows
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) {
+            const int f = __hip_atomic_exchange(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_flag[0] = f & 1; s_flag[1] = (f >> 1) & 1; s_flag[2] = (f >> 2) & 1;
+            __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next order
+        }
+        __syncthreads();
+        if (s_flag[0]) __atomic_thread_fence(__ATOMIC_ACQUIRE);           // (uniform, rare) the other half's field rows
+        for (int i = tid; i < N; i += blockDim.x) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_conv[k * ND + i] = __hip_atomic_load(gs + k * 128 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_sfc[i] = __hip_atomic_load(gs + 4 * 128 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     if (s_flag[2]) {                                                    // a carried value never arrived (internal error)
         if (tid == 0) {
             a.cv.status[b] = SOSRT_COL_INTERNAL;
@@ -795,8 +862,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     }
     // threads tid < N (the waves of chunk residue 0): direction tid
     const bool act = tid < N;
-    double rup_v = act ? s_conv[2 * nwc * 64 + tid] : 0.0, rup_i = act ? s_conv[3 * nwc * 64 + tid] : 1.0;
-    const double rdn_v = act ? s_conv[0 * nwc * 64 + tid] : 0.0, rdn_i = act ? s_conv[1 * nwc * 64 + tid] : 1.0;
+    double rup_v = act ? s_conv[2 * ND + tid] : 0.0, rup_i = act ? s_conv[3 * ND + tid] : 1.0;
+    const double rdn_v = act ? s_conv[0 * ND + tid] : 0.0, rdn_i = act ? s_conv[1 * ND + tid] : 1.0;
     if (s_flag[0]) {
         // A search of the upward sweep went past the lanes of the first lane group (spec:403-406 has no bound): redo that
         // sweep here, row by row, the row exchanged through LDS so that every direction can be a candidate (as the ring
@@ -809,7 +876,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         const double mu = tr ? g.mu[N + j] : 1.0;
         const double prmu = tr ? 1.0 / mu : 0.0;
         const int vo = (N + j) * 8;
-        double U = Bv, Jnext = 0;                                       // (thread tid < N holds direction tid)
+        // (one workgroup per column: thread tid < N holds direction tid; split: from the surface row, specular or none)
+        double U = SPLIT ? ((act && surface == SOSRT_SURFACE_SPECULAR) ? rho * s_sfc[N - 1 - tid] : 0.0) : Bv;
+        double Jnext = 0;
         bool missing = false;
         __syncthreads();
         for (int t = L - 1; t >= 0; --t) {
@@ -873,30 +942,24 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 }
 
 inline int scan_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
+template <bool SPLIT>
 inline size_t scan_lds_bytes(const Grid& g) {
-    const int nwc = (g.N + 63) / 64, ncw = nwc * SW, nwaves = ncw + SW;
-    const size_t doubles = (size_t)NST * STAGE + (size_t)nwc * CR * 64 + nwc * 64 + (size_t)kRingZones * scan_fixcap(g) * kFixMaxSrc + nwaves + 2 +
-                           g.L + 1 + (size_t)g.nsmall * g.L + 16 + 4 * nwc * 64 + (size_t)ncw * 2 * TC * 16;
-    return doubles * sizeof(double) + ((size_t)(nwc * CR + NST + NST * nwc) * sizeof(int) + 7) / 8 * 8;
+    using C = ScanCfg<SPLIT>;
+    const int nwc = SPLIT ? 1 : (g.N + 63) / 64, ncw = nwc * C::SW, nwaves = ncw + NLOAD, ND = (g.N + 63) / 64 * 64;
+    const size_t doubles = (size_t)C::NST * C::STAGE + (size_t)nwc * CR * 64 + ND + (size_t)kRingZones * scan_fixcap(g) * kFixMaxSrc + nwaves + 2 +
+                           g.L + 1 + (size_t)g.nsmall * g.L + 16 + 4 * ND + (size_t)ncw * 2 * TC * 16;
+    return doubles * sizeof(double) + ((size_t)(nwc * CR + C::NST + C::NST * nwc) * sizeof(int) + 7) / 8 * 8;
 }
 
-}  // namespace
-
-// Half rows of one 1-KiB piece (N <= 128, N even: 16-byte lanes), at most 64 chunks per sweep (the mask of the chunks
-// with a zone boundary), stages and tables within the LDS of a CU.
-bool transport_scan_ok(const Grid& g) {
-    if (g.N % 2 || g.N < 4 || g.N > 128) return false;
-    if ((g.L + TC - 1) / TC > 64) return false;
-    return scan_lds_bytes(g) <= kScanLdsBytes;
-}
-
-void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a) {
-    const int nwc = (a.g.N + 63) / 64;
-    const dim3 block((nwc * SW + SW) * 64);
-    const size_t shm = scan_lds_bytes(a.g);
+template <bool SPLIT>
+void launch_scan_t(hipStream_t s, dim3 grid, const TransportArgs& a) {
+    using C = ScanCfg<SPLIT>;
+    const int nwc = SPLIT ? 1 : (a.g.N + 63) / 64;
+    const dim3 block((nwc * C::SW + NLOAD) * 64);
+    const size_t shm = scan_lds_bytes<SPLIT>(a.g);
 #define SOSRT_SCAN_LAUNCH(ACC_, SAVED_)                                                                        \
     do {                                                                                                       \
-        auto kern = k_transport_scan<ACC_, SAVED_>;                                                            \
+        auto kern = k_transport_scan<ACC_, SAVED_, SPLIT>;                                                     \
         static bool big_lds = false;                                                                           \
         if (!big_lds) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -912,6 +975,28 @@ void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a) {
         SOSRT_SCAN_LAUNCH(false, false);
     }
 #undef SOSRT_SCAN_LAUNCH
+}
+
+}  // namespace
+
+// Half rows of one 1-KiB piece (N <= 128, N even: 16-byte lanes), at most 64 chunks per sweep (the mask of the chunks
+// with a zone boundary), stages and tables within the LDS of a CU.
+bool transport_scan_ok(const Grid& g) {
+    if (g.N % 2 || g.N < 4 || g.N > 128) return false;
+    if ((g.L + TC - 1) / TC > 64) return false;
+    return scan_lds_bytes<false>(g) <= kScanLdsBytes;
+}
+// two workgroups per column: two lane groups to deal, whole 16-byte lanes in a group's 512 bytes
+bool transport_scan_split_ok(const Grid& g) {
+    return transport_scan_ok(g) && g.N > 64 && g.N % 2 == 0 && scan_lds_bytes<true>(g) <= kScanLdsBytes;
+}
+size_t transport_scan_scratch_doubles() { return kScanScratch; }
+
+// a.scan_split: two workgroups per column (the grid is then twice the columns; specular surface or none; a.scan_scratch /
+// a.scan_sync: kScanScratch doubles and two zeroed ints per column of the batch)
+void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a) {
+    if (a.scan_split && a.accumulate) launch_scan_t<true>(s, dim3(2 * grid.x), a);
+    else launch_scan_t<false>(s, grid, a);
 }
 
 }  // namespace sosrt

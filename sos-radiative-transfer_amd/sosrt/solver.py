@@ -69,6 +69,9 @@ class Solver:
 
     # ---- setup -------------------------------------------------------------
     def set_stream(self, stream_handle: Optional[int]):
+        """Run on a caller's HIP stream (its integer handle).  0 / None = the handle's own non-blocking stream, which does
+        not synchronise with the legacy default stream -- and `torch.cuda.current_stream().cuda_stream` IS 0 for torch's
+        default stream: use an explicit `torch.cuda.Stream`, or synchronise around the calls."""
         check(lib().sosrt_set_stream(self._h, ctypes.c_void_p(stream_handle) if stream_handle else None))
 
     def synchronize(self):

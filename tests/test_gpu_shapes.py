@@ -192,6 +192,9 @@ def test_c5_full_size_batch_on_device():
     digests = []
     for _ in range(2):
         d_I.zero_()
+        # torch's default stream has the handle 0, which sosrt_set_stream reads as "the handle's own stream" (non-blocking:
+        # it does not wait for the legacy default stream): without this the fill may still be running under the solve
+        torch.cuda.synchronize()
         s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr(),
                        d_status=d_st.data_ptr())
         torch.cuda.synchronize()
