@@ -27,7 +27,9 @@
 // no barrier inside a sweep; every poll is bounded (SOSRT_COL_INTERNAL on expiry, never expected).
 //
 // Measured (MI355X, lone column, L = 200, N = 128): 41-42 us per order against 48 for the ring kernel; in-kernel stamps
-// (-DSOSRT_SCAN_STAMPS, tools/stamps_scan.py): 35 us, of which a computing wave spends a third waiting (stage, carried value).
+// (-DSOSRT_SCAN_STAMPS, tools/stamps_scan.py): 35 us, of which a computing wave spends a third waiting (stage, carried value)
+// -- the memory path of the one CU is the bound (six waves per lane group instead of four: the same time).  Hence the
+// SPLIT form below, two workgroups per column: 33-35 us.
 #include <type_traits>
 
 #include "../../include/sosrt.h"
