@@ -129,11 +129,12 @@ struct sosrt_handle {
     // convergence
     int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr, *d_erep = nullptr;
     unsigned long long* d_tauhash = nullptr;
-    // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel, 3 (default): the ring kernel for the
-    // orders below scan_from and the chunk-parallel kernel (transport_scan.hip) from there on, 4: the chunk-parallel kernel
-    // for every order.  The choice depends on the order index only, never on the live columns of the batch.
+    // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel, 3 (default): the ring kernel for
+    // launches with many live columns (HBM-bound) and the chunk-parallel kernel (transport_scan.hip) for launches with at
+    // most scan_cols (latency-bound), 4: the chunk-parallel kernel always.  The ring and the chunk-parallel kernel share
+    // their arithmetic (chunk-local recurrence), so the choice follows the live count without touching a column's bits.
     int transport_mode = 3;
-    int scan_from = 14;                  // SOSRT_SCAN_FROM: first order of the chunk-parallel kernel in mode 3
+    int scan_cols = 200;                 // SOSRT_SCAN_COLS
     bool ring_ok = false, scan_ok = false, scan_split_ok = false;
     int scan_split = 1;                  // SOSRT_SCAN_SPLIT: two workgroups per column when at most half as many columns are live as the device has CUs
     int cu_count = 0;
@@ -411,7 +412,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
         if (strcmp(ev, "full") == 0) h->contraction = SOSRT_CONTRACT_F64_FULL;
     if (const char* ev = getenv("SOSRT_TRANSPORT"))
         h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : (strcmp(ev, "scan") == 0 ? 4 : (strcmp(ev, "auto") == 0 ? 3 : 1)));
-    if (const char* ev = getenv("SOSRT_SCAN_FROM")) h->scan_from = atoi(ev);
+    if (const char* ev = getenv("SOSRT_SCAN_COLS")) h->scan_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_SCAN_SPLIT")) h->scan_split = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
@@ -1113,13 +1114,13 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             if (fast) {
                 // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
                 // need not stage those rows either
-                // the kernel of this order: by the order index alone (a column's bits must not depend on its batch)
-                const int fast_mode = (h->scan_ok && (h->transport_mode == 4 || (h->transport_mode == 3 && n >= h->scan_from))) ? 4 : ring_mode;
+                // the kernel of this launch: the chunk-parallel one while few columns are live (same bits as the ring kernel)
+                const int cols_now = tail_cols > 0 ? tail_cols : q.nb;
+                const int fast_mode = (h->scan_ok && (h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols))) ? 4 : ring_mode;
                 Grid gt = g;
                 if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
-                // chunk-parallel kernel: a column on two CUs while at most half as many columns are live as there are CUs (same
-                // arithmetic per direction, so the choice may follow the live count; the reflection must stay inside a half)
-                const int cols_now = tail_cols > 0 ? tail_cols : q.nb;
+                // chunk-parallel kernel: a column on two CUs while at most half as many columns are live as there are CUs (the
+                // reflection must stay inside a half)
                 const int split = (fast_mode == 4 && h->scan_split && h->scan_split_ok && 2 * cols_now <= h->cu_count &&
                                    (h->surface == SOSRT_SURFACE_SPECULAR || h->surface == SOSRT_SURFACE_NONE)) ? 1 : 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,

@@ -283,10 +283,20 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 cc[u] = rec_src(rec_hr(hk, nrmu), Jp, Ec[u], Jc[u]);
             }
             if (!SP) {
+                // Chunk-local form of the recurrence (the definition shared with transport_scan.hip, whose waves evaluate the
+                // chunks of a sweep at once: the same bits, so that which kernel transports a launch may follow the live
+                // count): d_u = E_u d_{u-1} + c_u, p_u = E_u p_{u-1} from d = 0, p = 1, then S_u = fma(S_in, p_u, d_u).
+                {
+                    double d = 0, p = 1, dl[TC], pl[TC];
 #pragma unroll
-                for (int u = 0; u < TC; ++u) {
-                    Dv = rec_step(Dv, Ec[u], cc[u]);
-                    v[u] = Dv;
+                    for (int u = 0; u < TC; ++u) {
+                        d = rec_step(d, Ec[u], cc[u]);
+                        p = u == 0 ? Ec[0] : rec_hr(p, Ec[u]);
+                        dl[u] = d; pl[u] = p;
+                    }
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) v[u] = rec_step(Dv, pl[u], dl[u]);
+                    Dv = v[TC - 1];
                 }
                 if (MODE == 2 && has_small) {
 #pragma unroll
@@ -452,10 +462,17 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 cc[u] = (SP && (t == zend0 || t == zend1)) ? 0.0 : src;
             }
             if (!SP) {
+                {   // chunk-local form, as in the downward sweep
+                    double d = 0, p = 1, dl[TC], pl[TC];
 #pragma unroll
-                for (int u = 0; u < TC; ++u) {
-                    U = rec_step(U, Ec[u], cc[u]);
-                    v[u] = U;
+                    for (int u = 0; u < TC; ++u) {
+                        d = rec_step(d, Ec[u], cc[u]);
+                        p = u == 0 ? Ec[0] : rec_hr(p, Ec[u]);
+                        dl[u] = d; pl[u] = p;
+                    }
+#pragma unroll
+                    for (int u = 0; u < TC; ++u) v[u] = rec_step(U, pl[u], dl[u]);
+                    U = v[TC - 1];
                 }
                 // spec:401-409.  The search almost always ends within the first few directions: the chunk goes
                 // through LDS and work item (uT, pT) tests candidate k = pT+1 of row uT, then produces direction

@@ -301,11 +301,11 @@ def test_two_column_groups_on_two_streams_are_bit_identical(monkeypatch):
     assert np.array_equal(a.I, b.I)                         # bit for bit
 
 
-def test_transport_kernel_by_order_index_keeps_batch_invariance(monkeypatch):
-    """Default mode: the ring kernel below order SOSRT_SCAN_FROM, the chunk-parallel kernel (chunk-local recurrences: other
-    rounding) from there on.  The switch is by the order index, so (1) a column solved alone, in a sub-batch or in the
-    whole batch has the same bits, with the switch in the middle of the solves (SCAN_FROM = 6) as with the default; (2)
-    against the ring kernel for every order the fields move by rounding only and the order counts not at all."""
+def test_transport_kernel_follows_the_live_count_with_the_same_bits(monkeypatch):
+    """Default mode: the ring kernel for launches with many live columns, the chunk-parallel kernel (one or two workgroups per
+    column) for launches with few.  The two share their arithmetic (chunk-local recurrence), so (1) the ring kernel alone,
+    the chunk-parallel kernel alone and any threshold between them give the same bits; (2) a column solved alone, in a
+    sub-batch or in the whole batch has the same bits."""
     from sosrt import main as M
     rng = np.random.default_rng(23)
     B = 40
@@ -315,7 +315,7 @@ def test_transport_kernel_by_order_index_keeps_batch_invariance(monkeypatch):
     kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=72, nb_angles=64, max_orders=200)
 
     def fresh(**env):
-        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_FROM"):
+        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_COLS", "SOSRT_SCAN_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -326,14 +326,13 @@ def test_transport_kernel_by_order_index_keeps_batch_invariance(monkeypatch):
     fresh(SOSRT_TRANSPORT="ring")
     ring = SOS_Aer_batch(mu0, taer, rho, **kw)
     assert (ring.status == 0).all() and ring.n.max() >= 14 and ring.n.min() < 14
-    for scan_from in ("6", None):
-        fresh(**({"SOSRT_SCAN_FROM": scan_from} if scan_from else {}))
+    for env in ({"SOSRT_TRANSPORT": "scan"}, {"SOSRT_TRANSPORT": "scan", "SOSRT_SCAN_SPLIT": "0"}, {"SOSRT_SCAN_COLS": "12"}, {}):
+        fresh(**env)
         whole = SOS_Aer_batch(mu0, taer, rho, **kw)
         assert np.array_equal(whole.n, ring.n) and (whole.status == 0).all()
-        assert rel_err(whole.I, ring.I) <= 1e-12
-        assert not np.array_equal(whole.I, ring.I)              # (the chunk-parallel kernel did run)
+        assert np.array_equal(whole.I, ring.I), env             # bit for bit
         sub = SOS_Aer_batch(mu0[7:19], taer[7:19], rho[7:19], **kw)
-        assert np.array_equal(sub.I, whole.I[7:19])             # bit for bit
+        assert np.array_equal(sub.I, whole.I[7:19])
         slow = int(np.argmax(ring.n))
         one = SOS_Aer_batch(mu0[slow:slow + 1], taer[slow:slow + 1], rho[slow:slow + 1], **kw)
         assert np.array_equal(one.I[0], whole.I[slow]) and one.n[0] == whole.n[slow]
@@ -343,8 +342,8 @@ def test_transport_kernel_by_order_index_keeps_batch_invariance(monkeypatch):
 @pytest.mark.parametrize("L,N", [(3, 8), (4, 64), (5, 128), (8, 32), (9, 128), (17, 100), (33, 64), (65, 128)])
 def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
     """The chunk-parallel kernel for every order on columns of fewer chunks than it has waves, ragged last chunks, one or
-    two lane groups, against the ring kernel: same order counts and statuses (IndexError, order budget), fields equal to
-    rounding (identical where every chunk has a zone boundary)."""
+    two lane groups, one or two workgroups per column, against the ring kernel: same order counts and statuses (IndexError,
+    order budget), same bits."""
     from sosrt import main as M
     rng = np.random.default_rng(100 * L + N)
     B = 5
@@ -366,7 +365,7 @@ def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
     assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
     live = a.status == 0
     if live.any():
-        assert rel_err(b.I[live], a.I[live]) <= 1e-12
+        assert np.array_equal(b.I[live], a.I[live])
 
 
 def test_reference_shipped_size_L800_N501():

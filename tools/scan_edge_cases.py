@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small and ragged shapes through the chunk-parallel transport kernel (every order) against the ring kernel: same order
-counts, fields equal to rounding.  python3 tools/scan_edge_cases.py"""
+counts, same bits (the two kernels share the chunk-local arithmetic).  python3 tools/scan_edge_cases.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sos-radiative-transfer_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +11,7 @@ from util import rel_err
 
 rng = np.random.default_rng(3)
 bad = 0
-for L in (3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 33, 64, 65):
+for L in (3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 33, 64, 65, 120, 200):
     for N in (4, 8, 32, 64, 100, 128):
         B = 5
         mu0 = rng.uniform(0.2, 1.0, B); taer = rng.choice([0.02, 0.12, 0.6], B); rho = rng.uniform(0.0, 0.8, B)
@@ -36,8 +36,9 @@ for L in (3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 33, 64, 65):
         ok = np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
         live = a.status == 0
         err = rel_err(b.I[live], a.I[live]) if live.any() else 0.0
-        ok = ok and err <= 1e-12
-        print("L=%3d N=%3d  n=%s status=%s  max rel diff %.1e %s" % (L, N, a.n.tolist(), a.status.tolist(), err, "ok" if ok else "MISMATCH"))
+        same_bits = bool(np.array_equal(a.I[live], b.I[live]))
+        ok = ok and err <= 1e-12 and (same_bits or os.environ.get("ALLOW_ROUNDING") == "1")
+        print("L=%3d N=%3d  n=%s status=%s  max rel diff %.1e same bits %s %s" % (L, N, a.n.tolist(), a.status.tolist(), err, same_bits, "ok" if ok else "MISMATCH"))
         bad += not ok
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
