@@ -12,9 +12,11 @@
 // steps plus everything else).  Chunks with a zone boundary, and the last chunk of a sweep, keep the serial form of the
 // ring kernel (state resets at zone ends, spec:359,378; blended restarts): they are single hops of the chain.
 //
-// The chunk-local form rounds differently from the serial one (1e-16 per step).  Which kernel transports an order is
-// therefore decided by the order index alone (api.hip: SOSRT_SCAN_FROM), never by how many columns of the batch are
-// live, so that a column's bits stay independent of its batch.
+// The chunk-local form rounds differently from the serial one (1e-16 per step).  It is therefore the definition for the ring
+// kernel as well (transport_ring.hip evaluates its plain chunks the same way, one after the other): the two kernels give
+// the same bits, and which of them transports a launch follows the number of live columns (api.hip: SOSRT_SCAN_COLS) --
+// the ring kernel where the launch is HBM-bound, this one where it is latency-bound -- while a column's result stays
+// independent of its batch.
 //
 // Roles.  A workgroup is  nwc * SW computing waves (lane group x chunk residue)  +  SW loader waves.  The rows of Jn and
 // of the attenuation table reach the computing waves through LDS: a pool of NST stages, chunk g (0 .. 2 NCH - 1 over the two
