@@ -1004,7 +1004,12 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     h->need_small = true;
     const int small_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;       // never equals an order tag
     bool small_published = false;
-    const bool fast = h->transport_mode >= 1 && h->fast_ok && h->max_nz <= kRingZones;   // more zones: the general kernel
+    // Columns of more than three zones go through the general kernel.  With the ring / chunk-parallel kernels available the
+    // other columns of such a batch keep theirs (two launches per order, each skipping the other's columns: a column's bits
+    // do not depend on its batch); with the register-streaming kernel the whole batch takes the general one.
+    const bool ring_like = h->transport_mode >= 2 && h->ring_ok;
+    const bool mixed = h->transport_mode >= 1 && h->fast_ok && h->max_nz > kRingZones && ring_like;
+    const bool fast = h->transport_mode >= 1 && h->fast_ok && (h->max_nz <= kRingZones || mixed);
     const int ring_mode = (h->transport_mode >= 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) {
         // one attenuation table per distinct optical-depth profile
@@ -1125,7 +1130,11 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                                    (h->surface == SOSRT_SURFACE_SPECULAR || h->surface == SOSRT_SURFACE_NONE)) ? 1 : 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0, split,
-                                 h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(), h->d_scan_sync + 2 * q.b0);
+                                 h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(), h->d_scan_sync + 2 * q.b0,
+                                 mixed ? 1 : 0);
+                if (mixed)                                 // the columns of more than three zones
+                    launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
+                                     h->d_E, 0, erep_g, 0, nullptr, 0, 0, nullptr, nullptr, 2);
                 if (h->N - 3 > 61 && fast_mode == 1)     // register-streaming kernel: a search that leaves wave 0 is redone by the
                     launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                      h->d_E, 2, erep_g);         // general kernel (flag cv.redo); the ring kernel redoes it itself

@@ -122,6 +122,10 @@ struct TransportArgs {
     int scan_split = 0;
     double* scan_scratch = nullptr;
     int* scan_sync = nullptr;
+    // A batch that mixes columns of up to three zones with columns of more: the ring / chunk-parallel kernel takes the first
+    // kind (zone_class 1), the general kernel the second (zone_class 2), each leaving the other's columns alone, so that a
+    // column keeps the kernel -- and the bits -- it would have alone.  0: every column.
+    int zone_class = 0;
 };
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
@@ -209,7 +213,8 @@ void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, cons
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
                       const double* Etab, int mode, const int* erep = nullptr, int live = 0, const int* live_list = nullptr,
-                      int ring_slots = 0, int scan_split = 0, double* scan_scratch = nullptr, int* scan_sync = nullptr);
+                      int ring_slots = 0, int scan_split = 0, double* scan_scratch = nullptr, int* scan_sync = nullptr,
+                      int zone_class = 0);
 bool transport_fast_ok(const Plan& plan);
 // erep (nullable): tables are built only for columns with erep[b] == b
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep);

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     } else if (ACC && !a.cv.active[b]) {
         return;
     }
+    if (a.zone_class == 1 && a.desc[b].nz > kRingZones) return;       // (the general kernel takes these)
     const Grid& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;

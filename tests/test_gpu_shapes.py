@@ -368,6 +368,45 @@ def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
         assert np.array_equal(b.I[live], a.I[live])
 
 
+def test_three_zone_columns_keep_their_bits_beside_columns_of_more_zones():
+    """A batch that mixes (clear, slab, clear) columns with two-layer columns: the latter go through the general transport
+    kernel, the former keep the ring / chunk-parallel kernel (two launches per order, each skipping the other's columns), so
+    a three-zone column has the bits it has in a batch of its own; the two-layer column matches the oracle."""
+    L, N = 48, 64
+    mu = inputs.direction_grid(N)
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, 0.6)
+    P0r, Pr = inputs.phase_function("hg", N, mu, 0.6, 0.7)
+    tau1, r1, mix1, dta1 = inputs.tau_profile_slabs(0.124, [(25, 17, 0.3)], 120, L)
+    two = [(60, 50, 0.2, 0.90), (25, 17, 0.4, 0.97)]
+    c2 = O.make_column_slabs(0.6, 120, two, L, 0.124, 0.3, 1.0, N, P0a, Pa, P0r, Pr)
+    nzmax = len(c2.zones)
+    assert nzmax == 5 and len(r1) == 3
+
+    def pad(x, fill=0):
+        return list(x) + [fill] * (nzmax - len(x))
+
+    s = Solver(L, N, max_batch=3, max_orders=100)
+    s.set_grid(mu); s.set_phase(Pa, Pr)
+    # the three-zone columns alone
+    rho = [0.1, 0.5]
+    s.set_columns_zones(np.tile(r1, (2, 1)), mix1, 0.6, rho, 1.0, 0.124 / L, 0.95, dta1, 0.424)
+    alone = s.solve(np.tile(tau1, (2, 1)), np.tile(P0a, (2, 1)), np.tile(P0r, (2, 1)))
+    # the same two around a two-layer column
+    zr0 = np.array([pad(r1), [z.r0 for z in c2.zones], pad(r1)], dtype=np.int32)
+    zmix = np.array([pad(mix1), [z.kind == "mix" for z in c2.zones], pad(mix1)], dtype=np.int32)
+    zwr = np.array([pad([0.95 if m else 0.0 for m in mix1]), [z.alb_aer for z in c2.zones], pad([0.95 if m else 0.0 for m in mix1])])
+    zdt = np.array([pad(dta1), [z.dtau_aer for z in c2.zones], pad(dta1)])
+    s.set_columns_zones(zr0, zmix, 0.6, [rho[0], c2.grd_alb, rho[1]], 1.0, 0.124 / L, zwr, zdt, [0.424, c2.tauStar_tot, 0.424], nz=[3, 5, 3])
+    mixed = s.solve(np.stack([tau1, c2.tau, tau1]), np.tile(P0a, (3, 1)), np.tile(P0r, (3, 1)))
+    assert (mixed.status == 0).all() and (alone.status == 0).all()
+    assert mixed.n[0] == alone.n[0] and mixed.n[2] == alone.n[1]
+    assert np.array_equal(mixed.I[0], alone.I[0]) and np.array_equal(mixed.I[2], alone.I[1])      # bit for bit
+    ref = O.solve_column(c2, literal=False)
+    assert int(mixed.n[1]) == ref.n
+    assert_close(mixed.I[1], ref.I, RTOL, "two-layer column beside three-zone columns")
+    s.close()
+
+
 def test_reference_shipped_size_L800_N501():
     """The size the reference ships (spec:33,57: nb_layers = 800, nb_angles = 501 -- odd and > 256, so the
     register-streaming transport kernel and the N >= 501 extrapolation tables) against the oracle, one column, at
