@@ -4,9 +4,11 @@
 One step = one pass of the hot path (I1 -> [Jn -> In] x orders, convergence test included) over
 one batch of synthetic columns whose inputs are already resident in HBM.  The workload is the
 BASELINE C4 sweep shape: 512 columns = 8 mu0 x 8 tau*_aer x 8 grd_alb, L=200, N=128, Rayleigh
-atmosphere + HG(g=0.7) aerosol stand-in (the EVA log-normal Mie phase function needs miepython,
-unavailable offline), specular surface, fp64.  P0(mu, mu0) of every column is built on the device
-(sosrt_phase_p0_dev) before the timed region.
+atmosphere + the aerosol of `--aerosol` (default `eva`: the log-normal Mie ensemble of the reference's EVA scenario,
+README.md:95-102, tabulated by sosrt/mie.py -- `miepython` is unavailable offline, so the table is parity-unpinned, the
+solve on it is checked against the oracle on identical inputs; `wildfire`: README.md:104-111; `hg`: the HG(0.7) stand-in
+of rounds 1-2), specular surface, fp64.  P0(mu, mu0) of every column is built on the device (sosrt_phase_p0_dev) before
+the timed region.
 
 Several GPUs (`--gpus N`): one process per GPU.  When no launcher environment is present (no WORLD_SIZE)
 the N rank processes are started from here through torch.distributed.run, before anything touches a GPU.
@@ -14,11 +16,15 @@ the N rank processes are started from here through torch.distributed.run, before
       single-scattering albedo); the TOA / surface radiances and order counts are gathered to rank 0 once
       per step.
   --scaling strong: ONE sweep (BASELINE configs[3]: 512 columns over the node, 64 per GPU at N = 8) dealt to
-      the ranks by expected work (sosrt.dist.shard_indices) and the whole fields gathered to rank 0 once per
-      step (sosrt.dist.gather_columns) -- RCCL over xGMI.
+      the ranks by expected work (sosrt.dist.GatherPlan) and the whole fields gathered to rank 0 once per
+      step -- ragged blocks, no padding, layout and receive buffers made once outside the step loop; `--gather field`:
+      torch.distributed point-to-point (ncclSend / ncclRecv under RCCL), `--gather abi`: the library's own sosrt_gather.
 No collective runs inside the order loop.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description).
+Prints ONE JSON line on rank 0 (see the contract in the task description).  Beside the headline (N = 1 only, outside its
+timed region, `--no-extras` skips them): `extras.c2` / `extras.c3` = one EVA column at N_mu = 128 / 256 (BASELINE
+configs[1], [2]: single-column latency), `extras.c5` = the 4096-column wildfire sweep at L = 400, N = 256 (configs[4]),
+each with its own check against the oracle.
 """
 import argparse
 import json
@@ -32,7 +38,16 @@ sys.path.insert(0, os.path.join(ROOT, "sos-radiative-transfer_amd"))
 import numpy as np
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix, vendor datasheet; the microarch guide lists no f64 row
-PMC_FILE = "r02_pmc_traffic.json"
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
+PMC_FILE = "r03_pmc_traffic.json"
+
+# what the sweeps vary around (README.md:95-111): slab altitudes, range of tau*_aer, aerosol single-scattering albedo
+SCENARIOS = {
+    "hg": dict(z=(25, 17), taer=(0.01, 1.0), alb_aer=0.97, label="HG(0.7) aerosol stand-in"),
+    "eva": dict(z=(25, 17), taer=(0.01, 1.0), alb_aer=0.97, label="EVA log-normal Mie aerosol (sigma=1.2, r_m=0.506 um, n=1.44; own Mie series, table parity-unpinned)"),
+    "wildfire": dict(z=(15, 14), taer=(0.0075 / 8, 0.0075 * 8), alb_aer=0.97,
+                     label="wildfire log-normal Mie aerosol (sigma=1.5, r_m=0.065 um, n=1.7+0.03j; own Mie series, table parity-unpinned)"),
+}
 
 
 def kernel_sources_sha():
@@ -45,24 +60,33 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def build_sweep(n_columns, L, N, rank, world, vary_albedo=True):
+def aerosol_phase(aerosol):
+    """(device kind, g, table or None) of the aerosol's scalar phase function."""
+    from sosrt import inputs
+    if aerosol == "hg":
+        return "hg", 0.7, None
+    return "table", 0.0, inputs.scenario_table(aerosol)
+
+
+def build_sweep(n_columns, L, N, rank, world, vary_albedo=True, aerosol="hg"):
     """Host-side description of one sweep (the per-column P0 rows are built on the device by the caller)."""
     from sosrt import inputs
+    sc = SCENARIOS[aerosol]
     side = max(1, round(n_columns ** (1 / 3)))
     mu0 = np.linspace(0.2, 1.0, side)
-    taer = np.geomspace(0.01, 1.0, side)
+    taer = np.geomspace(sc["taer"][0], sc["taer"][1], side)
     rho = np.linspace(0.0, 0.8, side)
     M0, TA, RH = (x.ravel()[:n_columns] for x in np.meshgrid(mu0, taer, rho, indexing="ij"))
     B = len(M0)
     mu = inputs.direction_grid(N)
-    iu, idn = inputs.slab_indices(120, 25, 17, L)
+    iu, idn = inputs.slab_indices(120, sc["z"][0], sc["z"][1], L)
     tau_atm = 0.124
-    alb_aer = float(np.linspace(0.97, 0.90, world)[rank]) if (world > 1 and vary_albedo) else 0.97
-    tau = np.stack([inputs.tau_profile(tau_atm, t, 120, 25, 17, L) for t in TA])
+    alb_aer = float(np.linspace(sc["alb_aer"], sc["alb_aer"] - 0.07, world)[rank]) if (world > 1 and vary_albedo) else sc["alb_aer"]
+    tau = np.stack([inputs.tau_profile(tau_atm, t, 120, sc["z"][0], sc["z"][1], L) for t in TA])
     P_atm = inputs.phase_function("rayleigh", N, mu, 0.5)[1]
-    P_aer = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
-    return dict(B=B, L=L, N=N, mu=mu, tau=tau, P_atm=P_atm, P_aer=P_aer, mu0=M0, taer=TA, rho=RH,
-                idx_up=iu, idx_down=idn, tau_atm=tau_atm, alb_aer=alb_aer)
+    P_aer = inputs.phase_function(aerosol, N, mu, 0.5, 0.7)[1]
+    return dict(B=B, L=L, N=N, mu=mu, tau=tau, P_atm=P_atm, P_aer=P_aer, mu0=M0, taer=TA, rho=RH, aerosol=aerosol,
+                idx_up=iu, idx_down=idn, z=sc["z"], tau_atm=tau_atm, alb_aer=alb_aer)
 
 
 def host_p0(w):
@@ -70,7 +94,8 @@ def host_p0(w):
     from sosrt import inputs
     cache = {}
     for m in np.unique(w["mu0"]):
-        cache[float(m)] = (inputs.phase_function("rayleigh", w["N"], w["mu"], m)[0], inputs.phase_function("hg", w["N"], w["mu"], m, 0.7)[0])
+        cache[float(m)] = (inputs.phase_function("rayleigh", w["N"], w["mu"], m)[0],
+                           inputs.phase_function(w.get("aerosol", "hg"), w["N"], w["mu"], m, 0.7)[0])
     return np.stack([cache[float(m)][0] for m in w["mu0"]]), np.stack([cache[float(m)][1] for m in w["mu0"]])
 
 
@@ -81,6 +106,11 @@ def take(w, idx):
         out[k] = np.ascontiguousarray(w[k][idx])
     out["B"] = len(idx)
     return out
+
+
+def oracle_p0(O, w, b):
+    kind, g, tab = aerosol_phase(w.get("aerosol", "hg"))
+    return (O.phase_p0("rayleigh", w["N"], w["mu"], float(w["mu0"][b])), O.phase_p0(kind, w["N"], w["mu"], float(w["mu0"][b]), g, tab))
 
 
 def oracle_column(O, w, b, P0a, P0r):
@@ -95,8 +125,7 @@ def _baseline_one(args):
     w, b = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sos_oracle as O
-    P0a = O.phase_rayleigh(w["N"], w["mu"], float(w["mu0"][b]))[0]
-    P0r = O.phase_hg(w["N"], w["mu"], float(w["mu0"][b]), 0.7)[0]
+    P0a, P0r = oracle_p0(O, w, b)
     t0 = time.perf_counter()
     s = O.solve_column(oracle_column(O, w, b, P0a, P0r), literal=True)
     return s.n - 1, time.perf_counter() - t0
@@ -142,7 +171,7 @@ def cpu_baseline(w, seconds_budget=20.0):
     if procs > 1:
         import multiprocessing as mp
         cols = np.linspace(0, B - 1, procs).astype(int)
-        wl = {k: w[k] for k in ("tau", "mu", "N", "L", "idx_up", "idx_down", "mu0", "rho", "alb_aer", "tau_atm", "taer", "P_atm", "P_aer")}
+        wl = {k: w[k] for k in ("tau", "mu", "N", "L", "idx_up", "idx_down", "mu0", "rho", "alb_aer", "tau_atm", "taer", "P_atm", "P_aer", "aerosol")}
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         t1 = time.perf_counter()
         with mp.get_context("spawn").Pool(procs) as pool:
@@ -154,6 +183,117 @@ def cpu_baseline(w, seconds_budget=20.0):
     return out
 
 
+class Lane:
+    """One handle + HIP stream + resident buffers for a sweep: inputs uploaded, P0 rows built on the device, `solve()`
+    enqueues one step."""
+
+    def __init__(self, w, dev, local_rank, max_orders, d_shared=None):
+        import torch
+        from sosrt.solver import Solver
+        B, L, N = w["B"], w["L"], w["N"]
+        self.w, self.dev, self.B, self.L, self.N = w, dev, B, L, N
+        self.stream = torch.cuda.Stream(device=dev)
+        self.s = Solver(L, N, max_batch=B, max_orders=max_orders, device=local_rank)
+        self.s.set_stream(self.stream.cuda_stream)
+        self.s.set_grid(w["mu"])
+        self.s.set_phase(w["P_atm"], w["P_aer"])
+        self.s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
+                           w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
+        if d_shared is None:
+            # the inputs of the path: tau uploaded; one P0 row per column built where the solve reads them
+            # (phase:86-103,148-165,245-262 on the device; outside the timed region, like the other inputs)
+            d_tau = torch.from_numpy(w["tau"]).to(dev)
+            d_mu0 = torch.from_numpy(np.ascontiguousarray(w["mu0"])).to(dev)
+            d_P0a = torch.empty((B, 2 * N), dtype=torch.float64, device=dev)
+            d_P0r = torch.empty((B, 2 * N), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(dev)
+            kind, g, tab = aerosol_phase(w.get("aerosol", "hg"))
+            if tab is not None:
+                self.s.set_phase_table(*tab)
+            self.s.phase_p0_device("rayleigh", d_mu0.data_ptr(), d_P0a.data_ptr(), B)
+            self.s.phase_p0_device(kind, d_mu0.data_ptr(), d_P0r.data_ptr(), B, g=g)
+            self.s.synchronize()
+            d_shared = (d_tau, d_P0a, d_P0r)
+        self.d_tau, self.d_P0a, self.d_P0r = d_shared
+        self.I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev)
+        self.n = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.st = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def shared(self):
+        return self.d_tau, self.d_P0a, self.d_P0r
+
+    def solve(self):
+        self.s.solve_device(self.d_tau.data_ptr(), self.d_P0a.data_ptr(), self.d_P0r.data_ptr(), self.I.data_ptr(), tol=1e-4,
+                            d_n_orders=self.n.data_ptr(), d_status=self.st.data_ptr())
+
+    def check(self, O, cols):
+        """Columns `cols` of the field the last step left on the device against the oracle (vectorised mode, same arithmetic as
+        the reference to rounding) on IDENTICAL inputs: the device-built P0 rows go into the oracle; they are compared with the
+        oracle's own evaluation beside that."""
+        w, N = self.w, self.N
+        n_host = self.n.cpu().numpy()
+        worst, same_n, p0_err = 0.0, True, 0.0
+        for b in cols:
+            P0a_d, P0r_d = self.d_P0a[b].cpu().numpy(), self.d_P0r[b].cpu().numpy()
+            P0a, P0r = oracle_p0(O, w, b)
+            p0_err = max(p0_err, float(np.max(np.abs(P0a_d - P0a) / P0a)), float(np.max(np.abs(P0r_d - P0r) / P0r)))
+            ref = O.solve_column(oracle_column(O, w, b, P0a_d, P0r_d), literal=False)
+            got = self.I[b].cpu().numpy()
+            scale = np.max(np.abs(ref.I))
+            sig = np.abs(ref.I) > 1e-9 * scale
+            err = max(float(np.max(np.abs(got - ref.I)[sig] / np.abs(ref.I)[sig])), float(np.max(np.abs(got - ref.I)) / scale))
+            worst = max(worst, err)
+            same_n = same_n and int(n_host[b]) == ref.n
+        return {"max_rel_err_vs_oracle": worst, "orders_match": bool(same_n), "p0_max_rel_err_vs_oracle": p0_err,
+                "tolerance": 1e-10, "ok": bool(worst <= 1e-10 and same_n and p0_err <= 1e-12)}
+
+    def close(self):
+        self.s.close()
+
+
+def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, max_orders=256):
+    """One more configuration of BASELINE.json beside the headline, outside its timed region: `steps` solves one at a time on
+    one stream, wall time, its own check."""
+    import torch
+    w = build_sweep(n_columns, L, N, 0, 1, aerosol=aerosol) if n_columns > 1 else None
+    if w is None:          # one column at the scenario's own values (README.md:95-111)
+        from sosrt import inputs
+        sc = SCENARIOS[aerosol]
+        taer = 0.120 if aerosol != "wildfire" else 0.0075
+        mu = inputs.direction_grid(N)
+        iu, idn = inputs.slab_indices(120, sc["z"][0], sc["z"][1], L)
+        w = dict(B=1, L=L, N=N, mu=mu, tau=inputs.tau_profile(0.124, taer, 120, sc["z"][0], sc["z"][1], L)[None],
+                 P_atm=inputs.phase_function_device("rayleigh", N, mu, 0.5, device=local_rank)[1],
+                 P_aer=inputs.phase_function_device(aerosol, N, mu, 0.5, 0.7, device=local_rank)[1],
+                 mu0=np.array([0.5]), taer=np.array([taer]), rho=np.array([0.15]), aerosol=aerosol, idx_up=iu, idx_down=idn,
+                 z=sc["z"], tau_atm=0.124, alb_aer=sc["alb_aer"])
+    ln = Lane(w, dev, local_rank, max_orders)
+    try:
+        ln.solve(); torch.cuda.synchronize(dev)                # warm-up
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ln.solve()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        n = ln.n.cpu().numpy()
+        orders = int((n - 1).sum())
+        out = {"workload": "%d column%s, L=%d, N=%d, Rayleigh + %s" % (w["B"], "" if w["B"] == 1 else "s", L, N, SCENARIOS[aerosol]["label"]),
+               "ms_per_solve": dt * 1e3, "columns_per_s": w["B"] / dt, "orders": orders, "max_order": int(n.max()),
+               "us_per_order_launch_group": dt * 1e6 / max(int(n.max()) - 1, 1), "not_converged": int((ln.st.cpu().numpy() != 0).sum()),
+               "steps": steps}
+        # single-GPU roofline of SURVEY 8(d) for this shape: max(t_flop, t_byte), both flop conventions
+        D = 2 * N
+        t_flop = 2.0 * L * D * D * orders / (FP64_MFMA_PEAK_TFLOPS * 1e12)
+        t_byte = 8.0 * L * D * (4 * orders + 2 * w["B"]) / (HBM_PEAK_GBS * 1e9)
+        out["roofline_frac_full_product"] = max(t_flop, t_byte) / dt
+        out["roofline_frac_executed"] = max(t_flop / 2, t_byte) / dt
+        if check_cols:
+            out["check"] = dict(ln.check(O, check_cols), columns=[int(b) for b in check_cols])
+        return out
+    finally:
+        ln.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,15 +302,18 @@ def main():
     ap.add_argument("--columns", type=int, default=512, help="columns per GPU")
     ap.add_argument("--layers", type=int, default=200)
     ap.add_argument("--angles", type=int, default=128)
+    ap.add_argument("--aerosol", choices=tuple(SCENARIOS), default="eva")
     ap.add_argument("--max-orders", type=int, default=256)
     ap.add_argument("--inflight", type=int, default=1, help="independent solves in flight (own handle + stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C3 / C5 figures beside the headline")
     ap.add_argument("--pipelined", type=int, default=3,
                     help="after the timed region, also measure the throughput with this many steps in flight on "
                          "separate streams (0: skip); reported beside the headline value, never instead of it")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--gather", choices=("digest", "field"), default=None,
-                    help="what rank 0 receives per step: TOA/surface rows + order counts, or the whole fields "
+    ap.add_argument("--gather", choices=("digest", "field", "abi"), default=None,
+                    help="what rank 0 receives per step: TOA/surface rows + order counts (digest), or the whole fields through "
+                         "torch.distributed point-to-point (field) or through the C ABI's sosrt_gather (abi) "
                          "(default: digest for weak scaling, field for strong)")
     ap.add_argument("--check-columns", type=int, default=3, help="columns compared with the oracle after the timed region")
     a = ap.parse_args()
@@ -200,6 +343,8 @@ def main():
     backend = os.environ.get("SOSRT_BENCH_BACKEND", "nccl")
     if os.environ.get("SOSRT_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    if a.gather == "abi" and world > 1 and backend != "nccl":
+        raise SystemExit("--gather abi needs RCCL (one GPU per rank); the gloo rehearsal uses --gather field")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -211,98 +356,97 @@ def main():
     import __graft_entry__ as ge
     ge.build()
     from sosrt import _lib
-    from sosrt.solver import Solver
-
     from sosrt import dist as sdist
+
     strong = a.scaling == "strong" and world > 1
-    w_all = build_sweep(a.columns, a.layers, a.angles, rank, world, vary_albedo=not strong)
+    w_all = build_sweep(a.columns, a.layers, a.angles, rank, world, vary_albedo=not strong, aerosol=a.aerosol)
     n_global = w_all["B"]
+    plan = None
     if strong:
-        # ONE sweep over the node: columns dealt by expected work, every rank gets about the same sum of orders
-        mine = sdist.shard_indices(n_global, world, rank, sdist.expected_orders(w_all["tau_atm"] + w_all["taer"], w_all["rho"]))
+        # ONE sweep over the node: columns dealt by expected work, every rank gets about the same sum of orders.  The layout
+        # of the gather follows from the deal alone: computed here, once, on every rank, without communication
+        plan = sdist.GatherPlan(n_global, world, sdist.expected_orders(w_all["tau_atm"] + w_all["taer"], w_all["rho"]))
+        mine = plan.mine(rank)
         w = take(w_all, mine)
     else:
         mine = np.arange(n_global)
         w = w_all
+        if world > 1 and a.gather in ("field", "abi"):
+            plan = sdist.GatherPlan(0, world)             # weak scaling, whole fields: every rank sends all its B columns
+            plan.n_columns, plan.counts = world * n_global, [n_global] * world
+            plan.offsets = np.arange(world + 1, dtype=np.int64) * n_global
     B, L, N = w["B"], w["L"], w["N"]
     D = 2 * N
     if B == 0:
         raise SystemExit("rank %d has no columns: --columns must be at least --gpus" % rank)
-    d_tau = torch.from_numpy(w["tau"]).to(dev)
-    d_mu0 = torch.from_numpy(np.ascontiguousarray(w["mu0"])).to(dev)
-    d_P0a = torch.empty((B, D), dtype=torch.float64, device=dev)
-    d_P0r = torch.empty((B, D), dtype=torch.float64, device=dev)
 
     # `inflight` independent solves may be in flight at once, each on its own handle and HIP stream:
     # the order loop of a sweep ends in a long tail of launches over its few slowest-converging
     # columns, which leaves most CUs idle; the next sweep's dense launches fill them.
-    class Lane:
-        def __init__(self):
-            self.stream = torch.cuda.Stream(device=dev)
-            self.s = Solver(L, N, max_batch=B, max_orders=a.max_orders, device=local_rank)
-            self.s.set_stream(self.stream.cuda_stream)
-            self.s.set_grid(w["mu"])
-            self.s.set_phase(w["P_atm"], w["P_aer"])
-            self.s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
-                               w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
-            self.I = torch.empty((B, L, D), dtype=torch.float64, device=dev)
-            self.n = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.st = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.done = torch.cuda.Event()
-
-        def solve(self):
-            """Enqueue one step on this lane's stream; returns (what rank 0 is to receive or None, completion event)."""
-            self.s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), self.I.data_ptr(), tol=1e-4,
-                                d_n_orders=self.n.data_ptr(), d_status=self.st.data_ptr())
-            dig = None
-            if world > 1 and a.gather == "digest":
-                with torch.cuda.stream(self.stream):
-                    dig = torch.cat([self.I[:, 0, N:], self.I[:, L - 1, :N], self.n.to(torch.float64)[:, None]], dim=1).contiguous()
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            return dig, ev
-
     torch.cuda.synchronize(dev)
-    lanes = [Lane() for _ in range(max(1, a.inflight))]
+    lanes = [Lane(w, dev, local_rank, a.max_orders)]
+    while len(lanes) < max(1, a.inflight):
+        lanes.append(Lane(w, dev, local_rank, a.max_orders, lanes[0].shared()))
     main_stream = torch.cuda.current_stream(dev)
-    # the inputs of the path that depend on mu0: one P0 row per column, built where the solve reads them
-    # (phase:86-103,148-165 on the device; outside the timed region, like the other inputs)
-    lanes[0].s.phase_p0_device("rayleigh", d_mu0.data_ptr(), d_P0a.data_ptr(), B)
-    lanes[0].s.phase_p0_device("hg", d_mu0.data_ptr(), d_P0r.data_ptr(), B, g=0.7)
-    lanes[0].s.synchronize()
+    on_gpu = backend == "nccl"
+    if world > 1 and a.gather == "abi":
+        for ln in lanes:
+            sdist._comm_for(ln.s, None, 0)
+
+    # per-step digest of a lane (weak scaling): equal blocks, receive buffers made once
+    dig_bufs = None
+    if world > 1 and a.gather == "digest" and rank == 0:
+        dig_bufs = [torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev if on_gpu else "cpu") for _ in range(world)]
 
     from concurrent.futures import ThreadPoolExecutor
     execs = [ThreadPoolExecutor(max_workers=1) for _ in lanes]       # a lane runs its steps in order
     gathered = {}
 
     def lane_step(i):
+        """Enqueue one step on lane i's stream; returns (what rank 0 is to receive or None, completion event)."""
         torch.cuda.set_device(local_rank)
-        return lanes[i].solve()
+        ln = lanes[i]
+        ln.solve()
+        send = None
+        if world > 1:
+            with torch.cuda.stream(ln.stream):
+                if a.gather == "digest":
+                    send = torch.cat([ln.I[:, 0, N:], ln.I[:, L - 1, :N], ln.n.to(torch.float64)[:, None]], dim=1).contiguous()
+                elif a.gather == "abi":
+                    # the C ABI's gather, on the lane's own stream behind the solve: ragged counts, the root's buffer made once
+                    got = sdist.gather_rows(ln.I, plan, dst=0, key="I%d" % i, via="abi", solver=ln.s)
+                    got_n = sdist.gather_rows(ln.n.to(torch.float64)[:, None].contiguous(), plan, dst=0, key="n%d" % i, via="abi", solver=ln.s)
+                    send = (got, got_n)
+        ev = torch.cuda.Event()
+        ev.record(ln.stream)
+        return send, ev
 
     def run_steps(k):
         """k steps dealt round-robin to the lanes.  With several ranks the results of every step are gathered to
-        rank 0 -- the only collective -- from this thread, in step order, behind the step's completion event:
-        per-column digests (TOA-up row, surface-down row, order count) or the whole fields."""
+        rank 0 -- the only collective -- in step order, behind the step's completion event: per-column digests (TOA-up row,
+        surface-down row, order count) or the whole fields."""
         futs = [(step % len(lanes), execs[step % len(lanes)].submit(lane_step, step % len(lanes))) for step in range(k)]
         for li, f in futs:
-            dig, ev = f.result()
-            if world > 1:
-                main_stream.wait_event(ev)
-                if a.gather == "field":
-                    ln = lanes[li]
-                    loc = {"I": ln.I, "n": ln.n}
-                    if backend != "nccl":             # gloo gathers host tensors
-                        ev.synchronize()
-                        loc = {k2: v.cpu() for k2, v in loc.items()}
-                    res = sdist.gather_columns(loc, mine if strong else np.arange(B), n_global if strong else B, dst=0)
-                    if rank == 0:
-                        gathered.clear(); gathered.update(res)
-                else:
-                    if backend != "nccl":
-                        ev.synchronize()
-                        dig = dig.cpu()
-                    bufs = [torch.empty_like(dig) for _ in range(world)] if rank == 0 else None
-                    dist.gather(dig, bufs, dst=0)
+            send, ev = f.result()
+            if world == 1:
+                continue
+            main_stream.wait_event(ev)
+            ln = lanes[li]
+            if a.gather == "abi":
+                if rank == 0:
+                    gathered["I"], gathered["n"] = send
+            elif a.gather == "field":
+                if not on_gpu:                    # gloo carries host tensors
+                    ev.synchronize()
+                got = sdist.gather_rows(ln.I if on_gpu else ln.I.cpu(), plan, dst=0, key="I")
+                got_n = sdist.gather_rows(ln.n if on_gpu else ln.n.cpu(), plan, dst=0, key="n")
+                if rank == 0:
+                    gathered["I"], gathered["n"] = got, got_n
+            else:
+                if not on_gpu:
+                    ev.synchronize()
+                    send = send.cpu()
+                dist.gather(send, dig_bufs, dst=0)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -330,35 +474,29 @@ def main():
         fo_ms += ln.s.profile_get(_lib.K_FIRST)[0]
         ln.s.profile_enable(False)
 
-    # Outside the timed region: sampled columns of the field the last timed step left on the device against the
-    # oracle (vectorised mode, same arithmetic as the reference to rounding).  Rank 0, its own columns.
+    # Outside the timed region: sampled columns of the field the last timed step left on the device against the oracle.
+    # Rank 0, its own columns.
     check = None
-    if rank == 0 and a.check_columns > 0:
+    O = None
+    if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import sos_oracle as O
-        I_host = lanes[(a.steps - 1) % len(lanes)].I
-        P0a_h, P0r_h = d_P0a.cpu().numpy(), d_P0r.cpu().numpy()
+    if rank == 0 and a.check_columns > 0:
+        last = lanes[(a.steps - 1) % len(lanes)]
         cols = sorted(set(np.linspace(0, B - 1, min(B, a.check_columns)).astype(int).tolist()))
-        worst, same_n, p0_err = 0.0, True, 0.0
-        for b in cols:
-            P0a = O.phase_rayleigh(N, w["mu"], float(w["mu0"][b]))[0]
-            P0r = O.phase_hg(N, w["mu"], float(w["mu0"][b]), 0.7)[0]
-            p0_err = max(p0_err, float(np.max(np.abs(P0a_h[b] - P0a) / P0a)), float(np.max(np.abs(P0r_h[b] - P0r) / P0r)))
-            ref = O.solve_column(oracle_column(O, w, b, P0a, P0r), literal=False)
-            got = I_host[b].cpu().numpy()
-            scale = np.max(np.abs(ref.I))
-            sig = np.abs(ref.I) > 1e-9 * scale
-            err = max(float(np.max(np.abs(got - ref.I)[sig] / np.abs(ref.I)[sig])), float(np.max(np.abs(got - ref.I)) / scale))
-            worst = max(worst, err)
-            same_n = same_n and int(n_host[b]) == ref.n
-        check = {"columns": [int(mine[b]) for b in cols], "max_rel_err_vs_oracle": worst, "orders_match": bool(same_n),
-                 "p0_max_rel_err_vs_oracle": p0_err, "tolerance": 1e-10, "ok": bool(worst <= 1e-10 and same_n)}
-        if world > 1 and a.gather == "field" and gathered:
-            # the gathered field holds every rank's columns in global order: rank 0's own must be where they belong
+        check = dict(last.check(O, cols), columns=[int(mine[b]) for b in cols])
+        if world > 1 and a.gather in ("field", "abi") and gathered:
+            # the gathered buffer holds the ranks' blocks one after the other; in global order (plan.restore) rank 0's own
+            # columns must be where they belong
             gI = gathered["I"]
-            sel = torch.as_tensor(np.asarray(mine if strong else np.arange(B))[cols], device=gI.device)
-            mineI = torch.stack([I_host[b] for b in cols]).to(gI.device)
+            if strong:
+                gI = plan.restore(gI)
+                sel = torch.as_tensor(np.asarray(mine)[cols], device=gI.device)
+            else:
+                sel = torch.as_tensor(np.asarray(cols), device=gI.device)
+            mineI = torch.stack([last.I[b] for b in cols]).to(gI.device)
             check["gather_places_columns"] = bool(torch.equal(gI[sel], mineI))
+            check["ok"] = bool(check["ok"] and check["gather_places_columns"])
 
     # Beside the headline (one step at a time, one stream: every kernel timing above is of a launch that
     # has the GPU to itself): the same steps with `--pipelined` of them in flight on separate streams and
@@ -366,7 +504,7 @@ def main():
     pipe = None
     if a.pipelined > 1 and len(lanes) == 1 and world == 1:
         while len(lanes) < a.pipelined:
-            lanes.append(Lane())
+            lanes.append(Lane(w, dev, local_rank, a.max_orders, lanes[0].shared()))
             execs.append(ThreadPoolExecutor(max_workers=1))
         psteps = max(a.steps, 2 * a.pipelined)
         run_steps(a.pipelined)
@@ -378,7 +516,7 @@ def main():
         pipe = {"steps_in_flight": a.pipelined, "steps": psteps, "value": B * psteps / dtp, "unit": "columns/s",
                 "ms_per_step": dtp / psteps * 1e3}
 
-    cpu_t = dev if backend == "nccl" else "cpu"
+    cpu_t = dev if on_gpu else "cpu"
     t = torch.tensor([dt], dtype=torch.float64, device=cpu_t)
     per_rank = torch.zeros(world, 2, dtype=torch.float64, device=cpu_t)
     per_rank[rank, 0] = B
@@ -398,24 +536,33 @@ def main():
         # flip-symmetric and the library runs the two N x N products (sosrt.h, sosrt_set_contraction) -- `achieved` counts
         # those, the rate in units of the full product is reported beside it.
         asym, uses_sym = lanes[0].s.phase_asymmetry()
-        full_flops = 2.0 * L * D * D * orders_per_step * a.steps
+        KO = orders_per_step * a.steps                            # column.orders in the timed region (this rank)
+        full_flops = 2.0 * L * D * D * KO
         flops = full_flops / 2 if uses_sym else full_flops
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        tr_gbs = 40.0 * L * D * orders_per_step * a.steps / (tr_ms * 1e-3) / 1e9 if tr_ms > 0 else 0.0
+        # The transport (Jn not fused): per element and order it reads Jn and I, writes In and I = 32 bytes.  (Its
+        # attenuation tables are shared per optical-depth profile and served from cache: not counted -- round 2 counted them.)
+        tr_bytes = 32.0 * L * D * KO
+        tr_gbs = tr_bytes / (tr_ms * 1e-3) / 1e9 if tr_ms > 0 else 0.0
         out = {
             "metric": "SOS columns/sec to 1e-4 convergence (Ntau=200, Nmu=128)",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C4 sweep: %s = mu0 x tau*_aer x grd_alb grid, L=%d, N=%d (D=%d), "
-                                   "Rayleigh atm + HG(0.7) aerosol stand-in, specular surface, tol 1e-4" % (
-                                       ("%d columns over %d GPUs" % (n_global, world)) if strong else ("%d columns/GPU" % B), L, N, D),
+                                   "Rayleigh atm + %s, specular surface, tol 1e-4" % (
+                                       ("%d columns over %d GPUs" % (n_global, world)) if strong else ("%d columns/GPU" % B), L, N, D,
+                                       SCENARIOS[a.aerosol]["label"]),
+                       "aerosol": a.aerosol,
                        "columns_per_gpu": [int(x) for x in per_rank[:, 0]] if world > 1 else B,
                        "orders_per_step": orders_per_step, "orders_per_step_per_rank": [int(x) for x in per_rank[:, 1]],
                        "max_order": int(n_host.max()),
                        "not_converged": int((st_host != 0).sum()), "inflight_solves": max(1, a.inflight),
                        "p0": "built on the device (sosrt_phase_p0_dev), outside the timed region",
-                       "gather": (a.gather + " to rank 0 once per step") if world > 1 else "none",
+                       "gather": ({"digest": "digest (TOA / surface rows, order counts) to rank 0 once per step, torch.distributed gather",
+                                   "field": "whole fields to rank 0 once per step, ragged point-to-point blocks (torch.distributed)",
+                                   "abi": "whole fields to rank 0 once per step through the C ABI (sosrt_gather: ncclSend / ncclRecv)"}[a.gather])
+                       if world > 1 else "none",
                        "parallelism": ("one sweep dealt to %d ranks by expected orders, gather only" % world) if strong else
                                       ("columns sharded x%d, gather only" % world)},
             "roofline": None, "roofline_other": None,
@@ -428,30 +575,60 @@ def main():
                   "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                   "avg_launch_ms": gemm_ms / max(gemm_launches, 1), "launches": gemm_launches,
                   "total_ms_per_step": gemm_ms / a.steps,
-                  "flops_per_column_order": flops / max(orders_per_step * a.steps, 1),
+                  "work_per_launch": flops / max(gemm_launches, 1), "work_unit": "flop",
+                  "flops_per_column_order": flops / max(KO, 1),
                   "form": ("flip-symmetric: two N x N products per row, L D^2 flops" if uses_sym else "full 2N x 2N product, 2 L D^2 flops"),
                   "matrix_asymmetry": asym,
                   "full_product_equivalent_tflops": full_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0}
-        # HBM-bound: reads Jn, E, I and writes In, I = 40 L D bytes per column.order
-        r_tr = {"bound": "hbm", "kernel": "k_transport_ring + k_transport_scan", "achieved": tr_gbs, "peak": 8000.0, "unit": "GB/s",
-                "frac": tr_gbs / 8000.0, "traffic": None, "avg_launch_ms": tr_ms / max(tr_launches, 1),
-                "launches": tr_launches, "total_ms_per_step": tr_ms / a.steps}
+        r_tr = {"bound": "hbm", "kernel": "k_transport_ring + k_transport_scan", "achieved": tr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": tr_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": tr_ms / max(tr_launches, 1),
+                "launches": tr_launches, "total_ms_per_step": tr_ms / a.steps,
+                "work_per_launch": tr_bytes / max(tr_launches, 1), "work_unit": "bytes (32 L D per column.order: read Jn, I; write In, I)"}
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of the same workload (the counters cannot be
         # read from inside this process).  The committed file names the source revision of the kernels it was
         # measured on; it is used only while those sources are unchanged, otherwise traffic stays null.
         try:
             with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 pmc = json.load(f)
-            if B == 512 and L == 200 and N == 128 and world == 1 and pmc.get("kernel_sources_sha") == kernel_sources_sha():
+            if (B == 512 and L == 200 and N == 128 and world == 1 and pmc.get("aerosol", "hg") == a.aerosol
+                    and pmc.get("kernel_sources_sha") == kernel_sources_sha()):
                 r_gemm["traffic"] = pmc["k_jn_gemm"]["hbm_bytes_per_launch"]
                 r_tr["traffic"] = pmc["k_transport"]["hbm_bytes_per_launch"]
                 r_gemm["traffic_unit"] = r_tr["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/%s)" % PMC_FILE
+                r_tr["frac_on_pmc_traffic"] = r_tr["traffic"] / (r_tr["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         except (OSError, KeyError, ValueError):
             pass
         # the roofline object is the kernel with the larger share of the timed region
         out["roofline"], out["roofline_other"] = (r_gemm, r_tr) if gemm_ms >= tr_ms else (r_tr, r_gemm)
+        # SURVEY 8(d), column level: the step against max(t_flop, t_byte) of one GPU's share.  t_flop in both conventions
+        # (2 L D^2 per column.order as 8d writes it / L D^2 as the symmetric form executes); t_byte = the compulsory
+        # 8 L D (4 K + 2) with Jn fused (+ 16 L D K while Jn round-trips HBM, as it does here).
+        ko1 = float(per_rank[:, 1].max())
+        b1 = float(per_rank[:, 0].max())
+        t_flop = 2.0 * L * D * D * ko1 / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+        t_byte = 8.0 * L * D * (4 * ko1 + 2 * b1) / (HBM_PEAK_GBS * 1e9) * 1e3
+        t_byte_unfused = t_byte + 16.0 * L * D * ko1 / (HBM_PEAK_GBS * 1e9) * 1e3
+        out["roofline_step"] = {"ms_per_step": ms_per_step, "t_flop_full_product_ms": t_flop, "t_flop_executed_ms": t_flop / (2 if uses_sym else 1),
+                                "t_byte_compulsory_ms": t_byte, "t_byte_with_jn_round_trip_ms": t_byte_unfused,
+                                "frac_full_product": max(t_flop, t_byte) / ms_per_step,
+                                "frac_executed": max(t_flop / (2 if uses_sym else 1), t_byte) / ms_per_step,
+                                "peaks": "%.1f TFLOP/s FP64 matrix, %.0f GB/s HBM" % (FP64_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS)}
         if pipe:
             out["pipelined"] = pipe
+        if world == 1 and not a.no_extras:
+            # the other single-GPU configurations of BASELINE.json, outside the headline's timed region
+            for ln in lanes:
+                ln.close()
+            lanes.clear()
+            torch.cuda.empty_cache()
+            ex = {}
+            try:
+                ex["c2"] = extra_case(O, dev, local_rank, 1, 200, 128, "eva", 20, [0])
+                ex["c3"] = extra_case(O, dev, local_rank, 1, 200, 256, "eva", 20, [0])
+                ex["c5"] = extra_case(O, dev, local_rank, 4096, 400, 256, "wildfire", 2, [16 * 16 * 5 + 16 * 9 + 4])
+            except Exception as e:                      # an extra must not take the headline line with it
+                ex["error"] = "%s: %s" % (type(e).__name__, e)
+            out["extras"] = ex
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)

@@ -64,11 +64,15 @@ int sosrt_version(void);
  * (plan queries only, no GPU is touched). */
 int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_t** out);
 int sosrt_destroy(sosrt_t* h);
-/* run on a caller-provided hipStream_t (e.g. the current torch stream); NULL = the handle's own stream.  The own stream is
- * non-blocking: it does NOT synchronise with the legacy default stream, and the default stream's handle IS NULL -- a
- * caller that enqueues work on the default stream (torch without an explicit stream) either passes an explicit stream
- * here or synchronises before and after the calls. */
+/* Streams.  A new handle enqueues on a stream of its own, created as a BLOCKING stream (hipStreamDefault): it orders against
+ * the legacy default stream, so a caller that fills its buffers on the default stream (handle NULL -- torch's default stream
+ * is that one) and then calls a `_dev` entry point gets the order it wrote, without an explicit synchronise.
+ * sosrt_set_stream runs the handle on the caller's hipStream_t instead; NULL names the legacy default stream itself, as it
+ * does everywhere in HIP (round 2 read NULL as "the handle's own stream", and that stream was non-blocking: a torch caller
+ * passing torch.cuda.current_stream().cuda_stream == 0 got work that raced its own fills -- gpurun_out/split_full.txt).
+ * sosrt_use_own_stream goes back to the handle's stream. */
 int sosrt_set_stream(sosrt_t* h, void* hip_stream);
+int sosrt_use_own_stream(sosrt_t* h);
 int sosrt_synchronize(sosrt_t* h);
 /* I_saved_out of the solves that follow holds `slots` orders per column ([B][slots][L][2N], 1 <= slots <=
  * max_orders; orders beyond are computed but not stored).  Default: max_orders.  The reference's list

@@ -736,6 +736,16 @@ def interpolate_table(mu_tab, p_tab, c):
     return np.where(idx == 0, p_tab[0], np.where(idx >= len(mu_tab), p_tab[-1], v))
 
 
+def phase_p0(kind, N, mu, mu0, g=0.0, table=None):
+    """P0(mu, mu0) alone (phase:86-103) for kind 'rayleigh' | 'hg' | 'table' -- the per-column input of a mu0 sweep, without
+    the O(D^2) matrix that `phase_rayleigh` & co. build beside it."""
+    fn = {"rayleigh": lambda c: (3 / 4) * (1 + c * c),
+          "hg": lambda c: (1 - g * g) / ((1 + g * g - 2 * g * c) ** 1.5),
+          "table": (lambda c: interpolate_table(table[0], table[1], c)) if table is not None else None}[kind]
+    P0 = _azimuth_average(fn, mu, np.array([mu0]))[:, 0] / (4 * np.pi)
+    return P0 / _trapz(P0, mu) * 2
+
+
 def phase_table(N, mu, mu0, mu_tab, p_tab):
     """phase:238-292 (fwc) for any tabulated phase function (fwc:3,173 is the reference's table)."""
     return _phase_pair(lambda c: interpolate_table(mu_tab, p_tab, c), N, mu, mu0)

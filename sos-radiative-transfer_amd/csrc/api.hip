@@ -87,7 +87,8 @@ struct sosrt_handle {
     double *d_z = nullptr;               // [L] altitude grid of the host epilogue
     double *d_tab = nullptr;             // [2][ntab] table of SOSRT_PHASE_TABLE
     int ntab = 0;
-    bool resident = false;               // d_tau / d_I hold the inputs / result of the last sosrt_solve
+    bool resident = false;               // d_tau / d_I hold the inputs / result of the last sosrt_solve (of resident_B columns)
+    int resident_B = 0;
     FixTab* d_fix = nullptr;
     int* d_small = nullptr;
     // device: columns
@@ -435,7 +436,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
         int e = 0;
         auto body = [&]() -> int {
             HIPCHK(hipSetDevice(device));
-            HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+            // the handle's own stream is a BLOCKING stream: it orders against the legacy default stream (handle NULL), which is
+            // where a caller without an explicit stream -- torch's default stream is that one -- fills and reads its buffers
+            HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault));
             h->stream = h->own_stream;
             if (h->prio2) {
                 int least = 0, greatest = 0;
@@ -542,7 +545,13 @@ int sosrt_destroy(sosrt_t* h) {
 
 int sosrt_set_stream(sosrt_t* h, void* s) {
     if (int e = need_gpu(h)) return e;
-    h->stream = s ? (hipStream_t)s : h->own_stream;
+    h->stream = (hipStream_t)s;              // NULL is the legacy default stream, as everywhere in HIP
+    return 0;
+}
+
+int sosrt_use_own_stream(sosrt_t* h) {
+    if (int e = need_gpu(h)) return e;
+    h->stream = h->own_stream;
     return 0;
 }
 
@@ -688,6 +697,7 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
                             const double* dtau_atm, const double* tauStar_tot) {
     const size_t mb = h->max_batch;
     const int L = h->L;
+    h->resident = false;                     // the descriptors of the resident field's columns are about to change
     std::vector<double> sc(7 * mb, 0.0);
     std::vector<int> slab, plain, iup(B, 0), idn(B, 0);
     auto zone_end = [&](int b, int z) { return z + 1 < nz[b] ? zr0[b * kMaxZones + z + 1] - 1 : L - 1; };
@@ -883,6 +893,7 @@ int sosrt_first_order(sosrt_t* h, int B, const double* tau, const double* P0_atm
     if (!tau || !P0_atm || !I1_out) return fail(SOSRT_E_INVALID, "null argument");
     if (h->geom == SOSRT_GEOM_THREE_ZONE && !P0_aer) return fail(SOSRT_E_INVALID, "three-zone geometry needs P0_aer");
     HIPCHK(hipSetDevice(h->device));
+    h->resident = false;                     // d_tau is overwritten
     const size_t n = (size_t)B * h->L * h->D;
     HIPCHK(hipMemcpyAsync(h->d_tau, tau, (size_t)B * h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_P0a, P0_atm, (size_t)B * h->D * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -923,6 +934,7 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     if (int e = check_ready(h, B, false)) return e;
     if (!tau || !Jn || !In_out) return fail(SOSRT_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->device));
+    h->resident = false;                     // d_tau is overwritten
     const size_t n = (size_t)B * h->L * h->D;
     HIPCHK(hipMemcpyAsync(h->d_tau, tau, (size_t)B * h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_Jn, Jn, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1024,6 +1036,11 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     }
+    // an error return after the fork still joins the internal stream back onto the caller's
+    auto bail = [&](int code) {
+        if (NG > 1 && hipEventRecord(h->ev_join, h->stream2) == hipSuccess) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+        return code;
+    };
 
     // Order loop (spec:309-458), per column group.  Converged columns are masked on the device (every kernel of an
     // order returns at once for them).  r_k = number of live columns of the group after order k is written to a
@@ -1074,7 +1091,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned it = 1; __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != small_tag; ++it) {
             if ((it & 0x3fff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-                return fail(SOSRT_E_HIP, "order loop: no progress for 120 s");
+                return bail(fail(SOSRT_E_HIP, "order loop: no progress for 120 s"));
             __builtin_ia32_pause();
         }
         h->need_small = slot[0] != 0;
@@ -1095,7 +1112,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             if (q.n >= h->max_orders) { q.done = true; --live_groups; continue; }
             if (q.n >= 2) {
                 const int live = wait_published(h, k, tagbase + q.n - 1);
-                if (live < 0) return live;
+                if (live < 0) return bail(live);
                 if (live == 0) { q.done = true; --live_groups; continue; }
                 q.known = live;
             }
@@ -1196,7 +1213,7 @@ int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, cons
         long long sum = 0;
         for (int b = 0; b < B; ++b) { sum += no[b] - 1; if (n_orders_out) n_orders_out[b] = no[b]; }
         h->last_sum_orders = sum;
-        h->resident = true;
+        h->resident = true; h->resident_B = B;
         return 0;
     };
     rc = body();
@@ -1225,6 +1242,7 @@ int sosrt_fluxes(sosrt_t* h, int B, const double* tau, const double* I, int beam
     if (int e = check_ready(h, B, false)) return e;
     if (!tau || !I || !flux_down || !flux_up) return fail(SOSRT_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->device));
+    h->resident = false;                     // d_tau and d_I are overwritten
     hipStream_t s = h->stream;
     const size_t n = (size_t)B * h->L * h->D, r = (size_t)B * h->L;
     HIPCHK(hipMemcpyAsync(h->d_tau, tau, r * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1259,7 +1277,8 @@ int sosrt_epilogue_dev(sosrt_t* h, int B, const double* d_tau, const double* d_I
 int sosrt_epilogue(sosrt_t* h, int B, int beam_norm, const double* z_profile, double* flux_down, double* flux_up,
                    double* diffusivity, double* heating_rate, double* net_toa) {
     if (int e = check_ready(h, B, false)) return e;
-    if (!h->resident) return fail(SOSRT_E_STATE, "no resident field: call sosrt_solve first");
+    if (!h->resident) return fail(SOSRT_E_STATE, "no resident field: call sosrt_solve first (and nothing that overwrites it since)");
+    if (B != h->resident_B) return fail(SOSRT_E_INVALID, "B=%d but the resident field is of %d columns", B, h->resident_B);
     if (heating_rate && !z_profile) return fail(SOSRT_E_INVALID, "the heating rate needs z_profile");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -1395,25 +1414,31 @@ int sosrt_gather(sosrt_t* h, int root, const long long* counts, const double* d_
     if (me == root && !d_recv) return fail(SOSRT_E_INVALID, "d_recv is null on the root");
     HIPCHK(hipSetDevice(h->device));
     const int kF64 = 8;                                      // ncclFloat64
+    // every exit below goes through GroupEnd: a group left open would swallow the communicator's next calls
+    int rc = 0, nrc = 0;
+    hipError_t hrc = hipSuccess;
     NCCLCHK(rccl().GroupStart());
     if (me == root) {
         size_t off = 0;
-        for (int r = 0; r < h->comm_world; ++r) {
+        for (int r = 0; r < h->comm_world && !nrc && hrc == hipSuccess; ++r) {
             if (counts[r] > 0) {
                 if (r == me) {
                     if (d_recv + off != d_send)
-                        HIPCHK(hipMemcpyAsync(d_recv + off, d_send, (size_t)counts[r] * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                        hrc = hipMemcpyAsync(d_recv + off, d_send, (size_t)counts[r] * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
                 } else {
-                    NCCLCHK(rccl().Recv(d_recv + off, (size_t)counts[r], kF64, r, h->comm, h->stream));
+                    nrc = rccl().Recv(d_recv + off, (size_t)counts[r], kF64, r, h->comm, h->stream);
                 }
             }
             off += (size_t)counts[r];
         }
     } else if (counts[me] > 0) {
-        NCCLCHK(rccl().Send(d_send, (size_t)counts[me], kF64, root, h->comm, h->stream));
+        nrc = rccl().Send(d_send, (size_t)counts[me], kF64, root, h->comm, h->stream);
     }
-    NCCLCHK(rccl().GroupEnd());
-    return 0;
+    const int erc = rccl().GroupEnd();
+    if (hrc != hipSuccess) rc = fail(SOSRT_E_HIP, "sosrt_gather: copy of the root's own block failed: %s", hipGetErrorString(hrc));
+    else if (nrc) rc = fail(SOSRT_E_HIP, "sosrt_gather: ncclSend/ncclRecv failed: %s", rccl().GetErrorString(nrc));
+    else if (erc) rc = fail(SOSRT_E_HIP, "sosrt_gather: ncclGroupEnd failed: %s", rccl().GetErrorString(erc));
+    return rc;
 }
 
 int sosrt_comm_destroy(sosrt_t* h) {

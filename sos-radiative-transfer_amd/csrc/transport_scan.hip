@@ -736,12 +736,16 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                     }
                 }
                 if (valid && (PM == 0 || (tblend && !(dir >= 1 && dir <= 8)))) {
+                    // SPLIT, the half without the mu -> 0+ lanes (part 1): its upward rows are what the OTHER workgroup reads back
+                    // (x_old, running total) if that one has to redo the sweep row by row, and part 1 cannot know: it leaves
+                    // them with write-through stores, so that they are in memory -- not dirty in this XCD's L2 -- when it arrives
+                    constexpr int WT = (SPLIT && PM == 0) ? 17 : 0;
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         if (SP && t0 - u < 0) continue;
                         const int so = (t0 - u) * RB;
-                        bstore(rIn, vo, so, v[u]);
-                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
+                        bstore_aux<WT>(rIn, vo, so, v[u]);
+                        if (ACC) bstore_aux<WT>(rI, vo, so, Ic[u] + v[u]);
                         if (SAVED) bstore(rS, vo, so, v[u]);
                         if (SP && t0 - u == 0) {
                             s_conv[2 * ND + dir] = v[u];
@@ -813,8 +817,14 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         // flags in global memory, and the one that arrives second runs the rest for the whole column.  The few exchanged
         // words go as device-scope atomics (performed at the coherence point: the workgroups may sit on different XCDs, whose
         // L2s are not coherent), acknowledged before the arrival counter moves -- no release / acquire fence, which would
-        // write back and invalidate a whole L2 under the other columns' feet.  Only a workgroup that asks for the row-by-row
-        // redo, which reads the other half's field rows, pays for the fence.
+        // write back and invalidate a whole L2 under the other columns' feet (measured: 111 us per launch with fences, 45
+        // with the atomics, at 128 live columns).  This rests on what gfx950 does -- an agent-scope (sc1) store is performed
+        // at memory before its vmcnt acknowledgement, and an agent-scope load misses the local L2 for lines another XCD may
+        // own -- not on the C++ memory model, which would ask for release / acquire on the counter.
+        // The row-by-row redo reads the OTHER half's field rows (x_old and the running total, to correct it).  Whichever
+        // workgroup runs it, those rows must be in memory by then: part 0 (the only one that can ask for the redo) writes
+        // its L2 back with a release fence in that rare case; part 1, which cannot know, stores its upward rows
+        // write-through in the first place (round 2 left them dirty in its L2: part 0 arriving last read stale rows).
         double* gs = a.scan_scratch + (size_t)b * kScanScratch;            // [4 test rows + surface row][128]
         int* sync = a.scan_sync + 2 * b;                                   // {arrivals, flags}
         __shared__ int s_last;
@@ -832,6 +842,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             if (f && lane == 0) __hip_atomic_fetch_or(sync + 1, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // acknowledged: the words are where the other workgroup reads them
         }
+        // part 1's write-through field rows of the upward sweep (see the stores): acknowledged by every wave before the arrival
+        if (part == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (part 0 is the only one that can raise the flag; it writes its own rows back with a fence, once, in that rare case)
         if (s_flag[0]) __atomic_thread_fence(__ATOMIC_RELEASE);           // (uniform) the redo will read this half's field rows
         __syncthreads();
         if (tid == 0) s_last = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;

@@ -35,6 +35,15 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int s
     v.y = (unsigned)__double2hiint(x);
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
+// the same with a cache policy (aux bits of the raw buffer intrinsics on gfx940+: 1 = sc0, 16 = sc1; 17 = both: a write-through
+// store, performed at the memory the other XCDs' L2s read from, acknowledged (vmcnt) once it is there)
+template <int AUX>
+__device__ __forceinline__ void bstore_aux(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x) {
+    u32x2 v;
+    v.x = (unsigned)__double2loint(x);
+    v.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, AUX);
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // two adjacent doubles per lane (16 bytes): half the vector-memory instructions of the 8-byte forms

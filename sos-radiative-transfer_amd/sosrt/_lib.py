@@ -29,6 +29,7 @@ SIGNATURES = {
     "sosrt_create": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "sosrt_destroy": (c_int, [c_void_p]),
     "sosrt_set_stream": (c_int, [c_void_p, c_void_p]),
+    "sosrt_use_own_stream": (c_int, [c_void_p]),
     "sosrt_synchronize": (c_int, [c_void_p]),
     "sosrt_set_saved_orders": (c_int, [c_void_p, c_int]),
     "sosrt_set_contraction": (c_int, [c_void_p, c_int]),

@@ -108,10 +108,24 @@ _bulk_cache = {}
 
 
 def _bulk(name, **kw):
+    """(mu_diff [6001], p [6001]): the ensemble phase function of a scenario as a table on the scattering cosine.  The
+    reference interpolates the table of every radius and integrates over the radii afterwards (phase:484-489, 738-744);
+    the interpolation is linear in the ordinates, so interpolating the radius-integrated table gives the same number."""
     key = (name,) + tuple(sorted(kw.items()))
     if key not in _bulk_cache:
-        _bulk_cache[key] = _mie.tabulated_phase(*_mie.log_normal_bulk_phase(**kw))
+        _bulk_cache[key] = _mie.log_normal_bulk_phase(**kw)
     return _bulk_cache[key]
+
+
+def scenario_table(name, lambda0=None, indx=None, r_m=None, sig=None):
+    """The (mu_diff, p) table of 'eva' | 'wildfire' (README.md:95-111 unless overridden): what `phase_function` evaluates on
+    the host and `phase_function_device` hands to the device table kernel (SOSRT_PHASE_TABLE).  Parity unpinned (own Mie
+    series, sosrt/mie.py)."""
+    kw = dict(_mie.SCENARIOS[name])
+    for k, v in (("wl", lambda0), ("m", indx), ("r_m", r_m), ("sig", sig)):
+        if v:
+            kw[k] = v
+    return _bulk(name, **kw)
 
 
 def _scalar_phase(name, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None):
@@ -124,17 +138,15 @@ def _scalar_phase(name, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=No
         mt, pt = fwc_table() if table is None else (np.asarray(table[0], dtype=np.float64), np.asarray(table[1], dtype=np.float64))
         return (lambda c: interpolate_table(mt, pt, c)), ("table", (mt, pt))
     if name in ("eva", "wildfire"):
-        kw = dict(_mie.SCENARIOS[name])
-        for k, v in (("wl", lambda0), ("m", indx), ("r_m", r_m), ("sig", sig)):
-            if v:
-                kw[k] = v
-        return _bulk(name, **kw), None
+        mt, pt = scenario_table(name, lambda0, indx, r_m, sig)
+        return (lambda c: interpolate_table(mt, pt, c)), ("table", (mt, pt))
     if name == "mie":
         if not (r and lambda0 and indx):
             raise ValueError("'mie' needs r, lambda0 and indx")
         x = 2 * np.pi * r / lambda0
-        mu_d = np.linspace(-1, 1, 6001)
-        return _mie.tabulated_phase(mu_d, _mie.i_unpolarized(complex(indx), x, mu_d)), None
+        mt = np.linspace(-1, 1, 6001)                       # phase:684-694 (compute_P's grid of scattering cosines)
+        pt = _mie.i_unpolarized(complex(indx), x, mt)
+        return (lambda c: interpolate_table(mt, pt, c)), ("table", (mt, pt))
     raise ValueError("unknown phase function %r" % (name,))
 
 
@@ -148,13 +160,16 @@ def phase_function(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=N
     return _azimuth_averaged(fn, mu, mu0)
 
 
-def phase_function_device(name, nb_angles, mu, mu0, g=0.0, table=None, matrix=True, device=0, solver=None):
+def phase_function_device(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None,
+                          matrix=True, device=0, solver=None):
     """The same on the GPU: `mu0` may be an array (one P0 row per column).  Returns (P0 [len(mu0), 2N] or [2N] for a
-    scalar mu0, P [2N, 2N] or None when matrix=False).  'iso' | 'rayleigh' | 'hg' | 'fwc' | 'table'."""
+    scalar mu0, P [2N, 2N] or None when matrix=False).  Every name `phase_function` takes: 'iso' | 'rayleigh' | 'hg' |
+    'fwc' | 'table' | 'mie' | 'eva' | 'wildfire' -- the Mie-derived ones as tables on the scattering cosine (the Mie series
+    and the size integration run once on the host, sosrt/mie.py; the O(D^2 * 50) azimuth averages on the device)."""
     from .solver import Solver
     scalar = np.ndim(mu0) == 0
     m = np.atleast_1d(np.asarray(mu0, dtype=np.float64))
-    kind, tab = ("iso", None) if name == "iso" else _scalar_phase(name, g, table=table)[1]
+    kind, tab = ("iso", None) if name == "iso" else _scalar_phase(name, g, r, lambda0, indx, r_m, sig, table)[1]
     s = solver or Solver(2, nb_angles, max_batch=max(1, min(m.size, 4096)), max_orders=1, device=device)
     try:
         if not s.same_grid(mu):

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from .inputs import direction_grid, phase_function, slab_indices, tau_profile
+from .inputs import direction_grid, slab_indices, tau_profile
 from .solver import Solver
 
 # the literals of SOS_Aer_main_specular.py:23-96
@@ -72,12 +72,28 @@ def _raise_status(status, nb_angles):
         raise RuntimeError("sosrt: internal error in the transport kernel (SOSRT_COL_INTERNAL)")
 
 
+def device_phase(s: Solver, name, mu0, g=0.0, mie=None, matrix=True):
+    """(P0 rows [len(mu0), 2N], P [2N, 2N] or None) of a named phase function, azimuth-averaged by the HIP kernels of solver
+    `s` (phase:79-133 and its siblings; the grid must be set).  `mie` = dict(r=, lambda0=, indx=, r_m=, sig=) for 'mie' /
+    'eva' / 'wildfire', whose phase function goes to the device as a table on the scattering cosine."""
+    from .inputs import _scalar_phase
+    kind, tab = ("iso", None) if name == "iso" else _scalar_phase(name, g, **(mie or {}))[1]
+    if tab is not None:
+        s.set_phase_table(*tab)
+    P0 = s.phase_p0(kind, mu0, g)
+    return P0, (s.phase_matrix(kind, g) if matrix else None)
+
+
 def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, alb_aer=1.0, z0=120, z_up=25, z_down=17,
                   nb_layers=200, nb_angles=128, atm_phase_fun="rayleigh", g_atm=0.0, aer_phase_fun="hg", g_aer=0.7,
+                  mie_atm=None, mie_aer=None,
                   P_atm=None, P_aer=None, P0_atm=None, P0_aer=None, surface="specular", tol=1e-4, max_orders=256,
                   save_orders=False, device=0, devices=None, raise_on_error=True, first_order="coded") -> BatchResult:
     """Solve B independent columns (arrays mu0, tauStar_aer, grd_alb broadcast to a common length;
-    tauStar_atm, alb_atm, alb_aer may be arrays too).  `first_order='readme'`: the README's Lambertian first order
+    tauStar_atm, alb_atm, alb_aer may be arrays too).  Phase functions that are not handed in as arrays are built on the
+    device (`device_phase`): any name of `inputs.phase_function`, `mie_atm` / `mie_aer` = dict(r=, lambda0=, indx=, r_m=,
+    sig=) for the Mie-derived ones ('eva' and 'wildfire' default to the README's scenarios).
+    `first_order='readme'`: the README's Lambertian first order
     (Solver.set_first_order; parity unpinned, single device).  `devices=[0, 1, ...]` shards the columns over several
     GPUs of the node, one worker process each, and gathers the fields (sosrt.dist.solve_on_devices; per-order
     fields are not gathered)."""
@@ -89,47 +105,17 @@ def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, 
         from .dist import solve_on_devices
         r = solve_on_devices(devices, mu0, tauStar_aer, grd_alb, tauStar_atm=tauStar_atm, alb_atm=alb_atm, alb_aer=alb_aer,
                              z0=z0, z_up=z_up, z_down=z_down, nb_layers=nb_layers, nb_angles=nb_angles,
-                             atm_phase_fun=atm_phase_fun, g_atm=g_atm, aer_phase_fun=aer_phase_fun, g_aer=g_aer, P_atm=P_atm,
+                             atm_phase_fun=atm_phase_fun, g_atm=g_atm, aer_phase_fun=aer_phase_fun, g_aer=g_aer,
+                             mie_atm=mie_atm, mie_aer=mie_aer, P_atm=P_atm,
                              P_aer=P_aer, P0_atm=P0_atm, P0_aer=P0_aer, surface=surface, tol=tol, max_orders=max_orders)
         if raise_on_error:
             _raise_status(r.status, int(nb_angles))
         return r
     if devices is not None and len(devices) == 1:
         device = int(devices[0])
-    mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer = np.broadcast_arrays(
-        *[np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in (mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer)])
-    B = mu0.shape[0]
-    L, N = int(nb_layers), int(nb_angles)
-    if z_down > z_up:
-        z_down, z_up = z_up, z_down
-    mu = direction_grid(N)
-    iu, idn = slab_indices(z0, z_up, z_down, L)
-    tau = np.stack([tau_profile(tauStar_atm[b], tauStar_aer[b], z0, z_up, z_down, L) for b in range(B)])
-    if P_atm is None:
-        P_atm = phase_function(atm_phase_fun, N, mu, 0.5, g_atm)[1]
-    if P_aer is None:
-        P_aer = phase_function(aer_phase_fun, N, mu, 0.5, g_aer)[1]
-    if P0_atm is None or P0_aer is None:
-        cache = {}
-        P0a = np.empty((B, 2 * N))
-        P0r = np.empty((B, 2 * N))
-        for b in range(B):
-            k = float(mu0[b])
-            if k not in cache:
-                cache[k] = (phase_function(atm_phase_fun, N, mu, k, g_atm)[0] if P0_atm is None else None,
-                            phase_function(aer_phase_fun, N, mu, k, g_aer)[0] if P0_aer is None else None)
-            P0a[b] = cache[k][0] if P0_atm is None else np.broadcast_to(P0_atm, (B, 2 * N))[b]
-            P0r[b] = cache[k][1] if P0_aer is None else np.broadcast_to(P0_aer, (B, 2 * N))[b]
-    else:
-        P0a = np.ascontiguousarray(np.broadcast_to(P0_atm, (B, 2 * N)))
-        P0r = np.ascontiguousarray(np.broadcast_to(P0_aer, (B, 2 * N)))
-    s = get_solver(L, N, B, max_orders, device)
-    if not s.same_grid(mu):
-        s.set_grid(mu)
-    if not s.same_phase(P_atm, P_aer):
-        s.set_phase(P_atm, P_aer)
-    s.set_columns(np.full(B, iu), np.full(B, idn), mu0, grd_alb, alb_atm, alb_aer,
-                  tauStar_atm / L, tauStar_aer / (idn + 1 - iu), tauStar_atm + tauStar_aer, surface=surface)
+    s, tau, P0a, P0r, mu, iu, idn, N = _prepare_batch(mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer, z0, z_up, z_down,
+                                                      nb_layers, nb_angles, atm_phase_fun, g_atm, aer_phase_fun, g_aer, mie_atm,
+                                                      mie_aer, P_atm, P_aer, P0_atm, P0_aer, surface, max_orders, device)
     s.set_first_order(first_order)
     try:
         r = s.solve(tau, P0a, P0r, tol=tol, save_orders=save_orders)
@@ -140,9 +126,78 @@ def SOS_Aer_batch(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, 
     return BatchResult(I=r.I, n=r.n, status=r.status, tau=tau, mu=mu, idx_up=iu, idx_down=idn, I_saved=r.I_saved)
 
 
+def _prepare_batch(mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer, z0, z_up, z_down, nb_layers, nb_angles,
+                   atm_phase_fun, g_atm, aer_phase_fun, g_aer, mie_atm, mie_aer, P_atm, P_aer, P0_atm, P0_aer, surface,
+                   max_orders, device, p0_on_host=True):
+    """Everything before the order loop (spec:23-96): optical-depth grids, direction grid, phase matrices folded into the
+    handle, per-column scalars.  Returns the solver and the per-column inputs."""
+    mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer = np.broadcast_arrays(
+        *[np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in (mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer)])
+    B = mu0.shape[0]
+    L, N = int(nb_layers), int(nb_angles)
+    if z_down > z_up:
+        z_down, z_up = z_up, z_down
+    mu = direction_grid(N)
+    iu, idn = slab_indices(z0, z_up, z_down, L)
+    tau = np.stack([tau_profile(tauStar_atm[b], tauStar_aer[b], z0, z_up, z_down, L) for b in range(B)])
+    s = get_solver(L, N, B, max_orders, device)
+    if not s.same_grid(mu):
+        s.set_grid(mu)
+    # the inputs of the path that are not handed in: P0(mu, mu0[b]) per column and P(mu, mu') on the device
+    # (phase:79-133; the Mie-derived functions as tables on the scattering cosine)
+    P0a = P0r = None
+    if P_atm is None or P0_atm is None:
+        P0a, Pm = device_phase(s, atm_phase_fun, mu0, g_atm, mie_atm, matrix=P_atm is None)
+        P_atm = Pm if P_atm is None else P_atm
+    if P_aer is None or P0_aer is None:
+        P0r, Pm = device_phase(s, aer_phase_fun, mu0, g_aer, mie_aer, matrix=P_aer is None)
+        P_aer = Pm if P_aer is None else P_aer
+    if P0_atm is not None:
+        P0a = np.ascontiguousarray(np.broadcast_to(P0_atm, (B, 2 * N)))
+    if P0_aer is not None:
+        P0r = np.ascontiguousarray(np.broadcast_to(P0_aer, (B, 2 * N)))
+    if not s.same_phase(P_atm, P_aer):
+        s.set_phase(P_atm, P_aer)
+    s.set_columns(np.full(B, iu), np.full(B, idn), mu0, grd_alb, alb_atm, alb_aer,
+                  tauStar_atm / L, tauStar_aer / (idn + 1 - iu), tauStar_atm + tauStar_aer, surface=surface)
+    return s, tau, P0a, P0r, mu, iu, idn, N
+
+
+def solve_batch_device(mu0, tauStar_aer, grd_alb, *, tauStar_atm=0.124, alb_atm=1.0, alb_aer=1.0, z0=120, z_up=25, z_down=17,
+                       nb_layers=200, nb_angles=128, atm_phase_fun="rayleigh", g_atm=0.0, aer_phase_fun="hg", g_aer=0.7,
+                       mie_atm=None, mie_aer=None, P_atm=None, P_aer=None, P0_atm=None, P0_aer=None, surface="specular",
+                       tol=1e-4, max_orders=256, device=0):
+    """`SOS_Aer_batch` with the RESULT LEFT ON THE DEVICE: returns ({"I": [B, L, 2N] float64, "n": [B] int32, "status": [B]
+    int32, "tau": [B, L]} as torch tensors on cuda:`device`, (mu, idx_up, idx_down)).  The solve is enqueued on torch's
+    current stream for that device, so the tensors are ordered like any torch result.  What `dist.solve_sharded` gathers."""
+    import torch
+    s, tau, P0a, P0r, mu, iu, idn, N = _prepare_batch(mu0, tauStar_aer, grd_alb, tauStar_atm, alb_atm, alb_aer, z0, z_up, z_down,
+                                                      nb_layers, nb_angles, atm_phase_fun, g_atm, aer_phase_fun, g_aer, mie_atm,
+                                                      mie_aer, P_atm, P_aer, P0_atm, P0_aer, surface, max_orders, device)
+    dev = torch.device("cuda", device)
+    B, L = tau.shape
+    with torch.cuda.device(dev):
+        s.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        try:
+            d_tau = torch.from_numpy(tau).to(dev)
+            d_P0a = torch.from_numpy(np.ascontiguousarray(P0a)).to(dev)
+            d_P0r = torch.from_numpy(np.ascontiguousarray(P0r)).to(dev)
+            d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev)
+            d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+            d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+            s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), tol=tol,
+                           d_n_orders=d_n.data_ptr(), d_status=d_st.data_ptr())
+        finally:
+            # the solver is cached and goes back to its own stream: drain this one first, so that the handle's internal
+            # buffers are not reused under the last launches (the order loop has already waited for all but the last two)
+            s.synchronize()
+            s.set_stream(None)
+    return {"I": d_I, "n": d_n, "status": d_st, "tau": d_tau}, (mu, iu, idn)
+
+
 def SOS_Aer_layers(mu0, grd_alb, slabs, *, tauStar_atm=0.124, alb_atm=1.0, z0=120, nb_layers=200, nb_angles=128,
-                   atm_phase_fun="rayleigh", g_atm=0.0, aer_phase_fun="hg", g_aer=0.7, P_atm=None, P_aer=None, surface="specular",
-                   tol=1e-4, max_orders=256, device=0, raise_on_error=True) -> BatchResult:
+                   atm_phase_fun="rayleigh", g_atm=0.0, aer_phase_fun="hg", g_aer=0.7, mie_atm=None, mie_aer=None, P_atm=None,
+                   P_aer=None, surface="specular", tol=1e-4, max_orders=256, device=0, raise_on_error=True) -> BatchResult:
     """Columns with SEVERAL aerosol layers (the reference has one): `slabs` = [(z_up, z_down, tauStar_aer,
     alb_aer), ...] from the top down, shared by the B columns of the arrays `mu0`, `grd_alb`.  Every formula of the path is
     evaluated per zone as the reference writes it for its three zones; one layer gives `SOS_Aer_batch`'s result bit for
@@ -154,25 +209,16 @@ def SOS_Aer_layers(mu0, grd_alb, slabs, *, tauStar_atm=0.124, alb_atm=1.0, z0=12
     tau, r0, mix, dta = tau_profile_slabs(tauStar_atm, [s[:3] for s in slabs], z0, L)
     zwr = np.zeros(len(r0))
     zwr[1::2] = [s[3] for s in slabs]
-    if P_atm is None:
-        P_atm = phase_function(atm_phase_fun, N, mu, 0.5, g_atm)[1]
-    if P_aer is None:
-        P_aer = phase_function(aer_phase_fun, N, mu, 0.5, g_aer)[1]
     s = get_solver(L, N, B, max_orders, device)
     if not s.same_grid(mu):
         s.set_grid(mu)
+    # P0(mu, mu0) per column, and the matrices that were not handed in, on the device
+    P0a, Pm = device_phase(s, atm_phase_fun, mu0, g_atm, mie_atm, matrix=P_atm is None)
+    P_atm = Pm if P_atm is None else P_atm
+    P0r, Pm = device_phase(s, aer_phase_fun, mu0, g_aer, mie_aer, matrix=P_aer is None)
+    P_aer = Pm if P_aer is None else P_aer
     if not s.same_phase(P_atm, P_aer):
         s.set_phase(P_atm, P_aer)
-    # P0(mu, mu0) per column on the device for the analytic phase functions, on the host otherwise
-    def p0(name, g):
-        if name in ("iso", "rayleigh", "hg", "fwc"):
-            if name == "fwc":
-                from .inputs import fwc_table
-                s.set_phase_table(*fwc_table())
-            return s.phase_p0({"fwc": "table"}.get(name, name), mu0, g)
-        cache = {float(m): phase_function(name, N, mu, float(m), g)[0] for m in np.unique(mu0)}
-        return np.stack([cache[float(m)] for m in mu0])
-    P0a, P0r = p0(atm_phase_fun, g_atm), p0(aer_phase_fun, g_aer)
     s.set_columns_zones(np.tile(r0, (B, 1)), mix, mu0, grd_alb, alb_atm, tauStar_atm / L, zwr, dta,
                         tauStar_atm + sum(x[2] for x in slabs), surface=surface)
     r = s.solve(np.tile(tau, (B, 1)), P0a, P0r, tol=tol)
@@ -191,16 +237,14 @@ def SOS_Aer(surface="specular", tol=1e-4, max_orders=256, P_atm=None, P0_atm=Non
         raise TypeError("unknown parameter(s): %s" % ", ".join(sorted(unknown)))
     p = dict(DEFAULTS, **overrides)
     N, L = int(p["nb_angles"]), int(p["nb_layers"])
-    mu = direction_grid(N)
-    if P_atm is None or P0_atm is None:
-        P0_atm, P_atm = phase_function(p["atm_phase_fun"], N, mu, p["mu0"], p["g_atm"], p["r_atm"], p["lambda0_atm"],
-                                       p["indx_atm"], p["r_m_atm"], p["sig_atm"])
-    if P_aer is None or P0_aer is None:
-        P0_aer, P_aer = phase_function(p["aer_phase_fun"], N, mu, p["mu0"], p["g_aer"], p["r_aer"], p["lambda0_aer"],
-                                       p["indx_aer"], p["r_m_aer"], p["sig_aer"])
+    mie = {k: dict(r=p["r_" + k], lambda0=p["lambda0_" + k], indx=p["indx_" + k], r_m=p["r_m_" + k], sig=p["sig_" + k])
+           for k in ("atm", "aer")}
     r = SOS_Aer_batch(p["mu0"], p["tauStar_aer"], p["grd_alb"], tauStar_atm=p["tauStar_atm"], alb_atm=p["alb_atm"],
                       alb_aer=p["alb_aer"], z0=p["z0"], z_up=p["z_up"], z_down=p["z_down"], nb_layers=L, nb_angles=N,
-                      P_atm=P_atm, P_aer=P_aer, P0_atm=np.asarray(P0_atm)[None], P0_aer=np.asarray(P0_aer)[None],
+                      atm_phase_fun=p["atm_phase_fun"], g_atm=p["g_atm"], aer_phase_fun=p["aer_phase_fun"], g_aer=p["g_aer"],
+                      mie_atm=mie["atm"], mie_aer=mie["aer"], P_atm=P_atm, P_aer=P_aer,
+                      P0_atm=None if P0_atm is None else np.asarray(P0_atm)[None],
+                      P0_aer=None if P0_aer is None else np.asarray(P0_aer)[None],
                       surface=surface, tol=tol, max_orders=max_orders, save_orders=True, device=device, first_order=first_order)
     n = int(r.n[0])
     return ColumnResult(I=r.I[0], I_saved=r.I_saved[0, :n].copy(), n=n, tau=r.tau[0], mu=r.mu, idx_up=r.idx_up,

@@ -69,10 +69,13 @@ class Solver:
 
     # ---- setup -------------------------------------------------------------
     def set_stream(self, stream_handle: Optional[int]):
-        """Run on a caller's HIP stream (its integer handle).  0 / None = the handle's own non-blocking stream, which does
-        not synchronise with the legacy default stream -- and `torch.cuda.current_stream().cuda_stream` IS 0 for torch's
-        default stream: use an explicit `torch.cuda.Stream`, or synchronise around the calls."""
-        check(lib().sosrt_set_stream(self._h, ctypes.c_void_p(stream_handle) if stream_handle else None))
+        """Run on a caller's HIP stream (its integer handle, e.g. `torch.cuda.current_stream().cuda_stream`).  0 is the
+        legacy default stream -- torch's default stream -- exactly as in HIP; None goes back to the handle's own stream (a
+        blocking stream: it too orders against the default stream)."""
+        if stream_handle is None:
+            check(lib().sosrt_use_own_stream(self._h))
+        else:
+            check(lib().sosrt_set_stream(self._h, ctypes.c_void_p(stream_handle) if stream_handle else None))
 
     def synchronize(self):
         check(lib().sosrt_synchronize(self._h))

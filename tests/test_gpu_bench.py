@@ -18,7 +18,7 @@ def _json_line(out):
 
 
 def test_bench_single_gpu_line():
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--columns", "64", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--columns", "64", "--no-cpu-baseline", "--no-extras"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
@@ -29,6 +29,33 @@ def test_bench_single_gpu_line():
     # the run checks itself: sampled columns against the oracle, outside the timed region
     assert d["check"]["ok"] and d["check"]["max_rel_err_vs_oracle"] <= 1e-10 and d["check"]["orders_match"]
     assert d["check"]["p0_max_rel_err_vs_oracle"] <= 1e-12
+    # the default workload carries the aerosol BASELINE names
+    assert d["config"]["aerosol"] == "eva" and "EVA log-normal Mie" in d["config"]["workload"]
+    # every frac follows from the line with one division
+    for r in (d["roofline"], d["roofline_other"]):
+        assert abs(r["achieved"] - r["work_per_launch"] / (r["avg_launch_ms"] * 1e-3) / (1e9 if r["unit"] == "GB/s" else 1e12)) < 1e-6 * r["achieved"]
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    tr = d["roofline"] if d["roofline"]["bound"] == "hbm" else d["roofline_other"]
+    assert abs(tr["work_per_launch"] * tr["launches"] - 32.0 * 200 * 256 * d["config"]["orders_per_step"] * d["steps"]) < 1.0
+    rs = d["roofline_step"]
+    assert 0 < rs["frac_executed"] <= rs["frac_full_product"] < 1
+
+
+def test_bench_extras_c2_c3_c5_and_hg_stand_in():
+    """The other single-GPU configurations of BASELINE.json beside the headline: one EVA column at N_mu = 128 and 256
+    (single-column latency), the 4096-column wildfire sweep at L = 400, N = 256, each checked against the oracle."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--columns", "27", "--no-cpu-baseline",
+                        "--aerosol", "hg", "--pipelined", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["aerosol"] == "hg" and d["check"]["ok"]
+    ex = d["extras"]
+    assert "error" not in ex, ex
+    for k, cols, N in (("c2", 1, 128), ("c3", 1, 256), ("c5", 4096, 256)):
+        e = ex[k]
+        assert e["check"]["ok"] and e["check"]["max_rel_err_vs_oracle"] <= 1e-10 and e["not_converged"] == 0, (k, e)
+        assert ("%d column" % cols) in e["workload"] and ("N=%d" % N) in e["workload"] and e["columns_per_s"] > 0
+    assert ex["c5"]["columns_per_s"] > 10 * ex["c3"]["columns_per_s"]          # a batch fills the GPU, a lone column cannot
 
 
 def test_bench_two_ranks_share_the_gpu():
@@ -36,7 +63,7 @@ def test_bench_two_ranks_share_the_gpu():
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--columns", "27",
-           "--inflight", "2"]
+           "--inflight", "2", "--aerosol", "hg"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = _json_line(r.stdout)

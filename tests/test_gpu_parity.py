@@ -144,6 +144,52 @@ def test_search_beyond_wave0_is_repaired(transport_mode):
     assert int(np.argmax(d2 > 1e-12)) + 1 > 64
 
 
+def test_split_scan_redo_reads_the_other_halfs_rows_fresh(monkeypatch):
+    """Whole columns whose upward mu -> 0+ search leaves the first 64 lanes in most orders (the phase matrices oscillate over
+    the first 70 upward directions), through the chunk-parallel kernel with TWO workgroups per column: the workgroup that
+    arrives second redoes the sweep row by row and corrects the running total with rows the OTHER workgroup -- possibly on
+    another XCD -- stored (part 1's rows were plain stores, dirty in its L2 when part 0 arrived last).  Same bits
+    as the ring kernel (one workgroup per column), on every repeat, and the oracle's field."""
+    N, L = 128, 40
+    mu = inputs.direction_grid(N)
+    j = np.arange(N)
+    c = np.ones(2 * N)
+    c[N:] = np.where(j < 70, 1 + 0.3 * (-1.0) ** j, 1.0)
+    cols = [(0.6, 0.3, 0.3), (0.6, 0.9, 0.6), (0.6, 0.05, 0.1), (0.35, 0.5, 0.45)]
+    P_atm = O.phase_rayleigh(N, mu, 0.5)[1] * c[:, None]
+    P_aer = O.phase_hg(N, mu, 0.5, 0.7)[1] * c[:, None]
+    m0, ta, rh = (np.array(x) for x in zip(*cols))
+    P0a = np.stack([O.phase_rayleigh(N, mu, m)[0] for m in m0])
+    P0r = np.stack([O.phase_hg(N, mu, m, 0.7)[0] for m in m0])
+    iu, idn = inputs.slab_indices(120, 40, 12, L)
+    tau = np.stack([inputs.tau_profile(0.124, t, 120, 40, 12, L) for t in ta])
+    out = {}
+    for mode, reps in (("ring", 1), ("scan", 6)):
+        monkeypatch.setenv("SOSRT_TRANSPORT", mode)        # read when the handle is created
+        s = Solver(L, N, max_batch=len(cols), max_orders=200)
+        try:
+            s.set_grid(mu); s.set_phase(P_atm, P_aer)
+            assert not s.phase_asymmetry()[1]              # not flip-symmetric: the full product runs
+            s.set_columns(np.full(len(cols), iu), np.full(len(cols), idn), m0, rh, 1.0, 0.95, 0.124 / L, ta / (idn + 1 - iu), 0.124 + ta)
+            out[mode] = [s.solve(tau, P0a, P0r) for _ in range(reps)]
+        finally:
+            s.close()
+    ring = out["ring"][0]
+    assert np.all(ring.status == _lib.COL_OK)
+    for r in out["scan"]:
+        assert np.array_equal(r.n, ring.n) and np.array_equal(r.status, ring.status)
+        assert np.array_equal(r.I, ring.I)                 # bit for bit, every repeat
+    long_blends = 0
+    for b, (a, t, g) in enumerate(cols):
+        col = O.make_column(a, 120, 40, 12, L, 0.124, t, g, 1.0, 0.95, N, P0a[b], P_atm, P0r[b], P_aer)
+        ref = O.solve_column(col, literal=False)
+        assert ring.n[b] == ref.n
+        assert_close(ring.I[b], ref.I, RTOL, "column %d" % b)
+        # the blend really went beyond lane 63 in several orders of this column: rows exactly linear in mu up to lane ~70
+        long_blends += sum(int(np.argmax(np.abs(np.diff(In[L // 2, N:], 2)) > 1e-12)) + 1 > 64 for In in ref.I_saved)
+    assert long_blends >= 12
+
+
 def test_index_error_like_the_reference():
     N, L = 16, 6
     mu = inputs.direction_grid(N)

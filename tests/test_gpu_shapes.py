@@ -1,5 +1,7 @@
 """More shapes through the HIP path: the BASELINE configs C3 (N=256) and C5 (L=400, N=256), direction
 counts that are not a multiple of the wavefront, thin slabs, the order budget.  Needs an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -191,10 +193,7 @@ def test_c5_full_size_batch_on_device():
     d_n = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
     digests = []
     for _ in range(2):
-        d_I.zero_()
-        # torch's default stream has the handle 0, which sosrt_set_stream reads as "the handle's own stream" (non-blocking:
-        # it does not wait for the legacy default stream): without this the fill may still be running under the solve
-        torch.cuda.synchronize()
+        d_I.zero_()              # on torch's default stream = the legacy default stream = what set_stream(0) names: ordered
         s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr(),
                        d_status=d_st.data_ptr())
         torch.cuda.synchronize()
@@ -211,6 +210,52 @@ def test_c5_full_size_batch_on_device():
     ref = O.solve_column(col, literal=False)
     assert int(d_n[b].item()) == ref.n
     assert_close(d_I[b].cpu().numpy(), ref.I, RTOL, "column %d" % b)
+    s.close()
+
+
+@pytest.mark.parametrize("stream", ["default", "own", "torch"])
+def test_solve_is_ordered_against_the_callers_fills_without_a_synchronise(stream):
+    """The failure of round 2 (gpurun_out/split_full.txt): a torch caller fills its buffers on torch's default stream, whose
+    handle is 0, and solves without a synchronise.  sosrt_set_stream(h, 0) now names that stream (round 2: the handle's own
+    non-blocking stream, which raced the fill), the handle's own stream is a blocking stream, and an explicit torch stream
+    is ordered by the caller.  Large fills right before the solve, field and order counts bit-reproducible over repeats and
+    equal to a synchronised run."""
+    import torch
+    import bench
+    L, N = 200, 128
+    w = bench.build_sweep(216, L, N, 0, 1)
+    B = w["B"]
+    dev = torch.device("cuda", 0)
+    P0a_h, P0r_h = bench.host_p0(w)
+    s = Solver(L, N, max_batch=B, max_orders=128)
+    side = torch.cuda.Stream(device=dev) if stream == "torch" else None
+    s.set_stream({"default": torch.cuda.current_stream(dev).cuda_stream, "own": None}.get(stream, side.cuda_stream if side else None))
+    s.set_grid(w["mu"]); s.set_phase(w["P_atm"], w["P_aer"])
+    s.set_columns(np.full(B, w["idx_up"]), np.full(B, w["idx_down"]), w["mu0"], w["rho"], 1.0, w["alb_aer"],
+                  w["tau_atm"] / L, w["taer"] / (w["idx_down"] + 1 - w["idx_up"]), w["tau_atm"] + w["taer"])
+    h_tau, h_P0a, h_P0r = (torch.from_numpy(np.ascontiguousarray(x)).pin_memory() for x in (w["tau"], P0a_h, P0r_h))
+    d_tau = torch.empty((B, L), dtype=torch.float64, device=dev)
+    d_P0a = torch.empty((B, 2 * N), dtype=torch.float64, device=dev); d_P0r = torch.empty_like(d_P0a)
+    d_I = torch.empty((B, L, 2 * N), dtype=torch.float64, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    junk = torch.empty((1 << 27,), dtype=torch.float64, device=dev)          # 1 GiB: the fills take a while
+    outs = []
+    for rep in range(3):
+        ctx = torch.cuda.stream(side) if side is not None else torch.cuda.stream(torch.cuda.current_stream(dev))
+        with ctx:
+            # poison, then the real inputs, all asynchronous on the caller's stream, and NO synchronise before the solve
+            junk.fill_(float(rep)); d_I.fill_(float("nan")); d_tau.fill_(float("nan")); d_n.fill_(-1)
+            d_tau.copy_(h_tau, non_blocking=True); d_P0a.copy_(h_P0a, non_blocking=True); d_P0r.copy_(h_P0r, non_blocking=True)
+            s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr())
+            # the caller reads on its stream right away, again without a synchronise of its own
+            outs.append((d_I.clone(), d_n.clone()))
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    assert bool(torch.isfinite(outs[0][0]).all()) and int(outs[0][1].min()) >= 2
+    ref = SOS_Aer_batch(w["mu0"], w["taer"], w["rho"], tauStar_atm=w["tau_atm"], alb_aer=w["alb_aer"], nb_layers=L, nb_angles=N,
+                        P_atm=w["P_atm"], P_aer=w["P_aer"], P0_atm=P0a_h, P0_aer=P0r_h, max_orders=128)
+    assert np.array_equal(outs[0][1].cpu().numpy(), ref.n)
+    assert np.array_equal(outs[0][0].cpu().numpy(), ref.I)                  # the synchronous host-pointer solve, bit for bit
     s.close()
 
 
@@ -449,6 +494,41 @@ def test_rccl_entry_points_world_of_one():
         s.gather_device(3, [1000], x.data_ptr(), y.data_ptr())
     s.comm_destroy()
     s.close()
+
+
+def test_sharded_solve_through_the_abi_gather_world_of_one():
+    """`dist.solve_sharded(gather="abi")`: the shard is solved into device memory, packed, sent through sosrt_gather
+    (RCCL; a communicator of ONE rank here -- RCCL refuses two ranks on one GPU, so more than one rank of this path stays
+    unmeasured on this box) into the root's device buffer, restored to global order, and copied to the host once.  In a
+    child process (it initialises a process group); same bits as `SOS_Aer_batch`."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, 'sos-radiative-transfer_amd'))
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from sosrt.main import SOS_Aer_batch
+from sosrt.dist import solve_sharded
+rng = np.random.default_rng(11)
+B = 9
+mu0, taer, rho = rng.uniform(0.2, 1.0, B), rng.choice([0.02, 0.3, 0.9], B), rng.uniform(0.0, 0.8, B)
+kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=40, nb_angles=64, max_orders=200)
+one = SOS_Aer_batch(mu0, taer, rho, **kw)
+for via in ('abi', 'torch'):
+    two = solve_sharded(mu0, taer, rho, gather=via, **kw)
+    assert np.array_equal(one.n, two.n) and np.array_equal(one.status, two.status) and np.array_equal(one.tau, two.tau), via
+    assert np.array_equal(one.I, two.I), via
+dist.destroy_process_group()
+print('SHARDED_OK')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, root, str(30500 + os.getpid() % 1000)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 def test_float_contraction_is_an_opt_in_that_misses_the_parity_bar():

@@ -46,8 +46,8 @@ for trial in range(int(os.environ.get("TRIALS", "3"))):
     ref = None
     for rep in range(int(os.environ.get("REPS", "3"))):
         d_I.zero_()
-        if os.environ.get("SYNC_AFTER_ZERO", "1") == "1":
-            torch.cuda.synchronize()      # torch's default stream has the handle 0 = "the handle's own stream" for sosrt_set_stream
+        if os.environ.get("SYNC_AFTER_ZERO", "0") == "1":     # (round 2: needed, set_stream(0) meant a non-blocking stream; round 3: 0 = the default stream)
+            torch.cuda.synchronize()
         s.solve_device(d_tau.data_ptr(), d_P0a.data_ptr(), d_P0r.data_ptr(), d_I.data_ptr(), d_n_orders=d_n.data_ptr(), d_status=d_st.data_ptr())
         torch.cuda.synchronize()
         cur = (d_I.clone(), d_n.clone())
