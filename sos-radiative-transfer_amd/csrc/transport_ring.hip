@@ -91,11 +91,12 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
     double* s_x = s_S + (size_t)g.nsmall * L;                  // [TC][16] the 16 lanes of a mu -> 0 neighbourhood, rows of a chunk
     double* s_prmu = s_x + TC * 16;                            // [16] 1/mu of the first upward directions
+    int* s_nf = reinterpret_cast<int*>(s_prmu + 16);           // [(L + 31) / 32] rows whose mu -> 0+ search left wave 0 (finish_flagged_rows)
     // lanes (of the wave that holds them) of the two neighbourhoods: the last 16 downward directions, the first 16 upward ones
     const int xb_dn = max(((N - 1) & 63) - 15, 0);
     // (all per-column tables are compact: with the ring and the row buffers a workgroup needs less than half the LDS of a
     // CU, so two columns share one -- or one column and two workgroups of the contraction of the other column group)
-    __shared__ int s_flag[2];                                  // [0] redo with the general kernel, [1] IndexError
+    __shared__ int s_flag[3];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] some row is flagged in s_nf
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
     const int zend0 = nz > 1 ? dg->r1[0] : -9, zend1 = nz > 2 ? dg->r1[1] : -9;
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             const FixTab& src = g.fix[dg->fixtab[zz]];
             for (int i = tid; i < fixcap * kFixMaxSrc; i += ncomp) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
         }
-        if (tid < 2) s_flag[tid] = 0;
+        if (tid < 3) s_flag[tid] = 0;
+        for (int i = tid; i < (L + 31) / 32; i += ncomp) s_nf[i] = 0;
         const double* __restrict__ tau = a.tau + (size_t)b * L;
         for (int t = tid; t <= L; t += ncomp) s_hd[t] = (t == 0 || t == L) ? 0.0 : (tau[t] - tau[t - 1]) * 0.5;
         if (tid < 16) s_prmu[tid] = (tid > 0 && tid < N) ? 1.0 / g.mu[N + tid] : 0.0;
@@ -435,13 +437,21 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         const int last_cand = min(N - 3, 61);
         bool notfound = false;
         double U = Bv, Jnext = 0;
-        // spec:401-409 for one row held across wave 0: x is the raw row, returns the blended value
-        auto blend = [&](double x) {
+        // spec:401-409 for one row (t) held across wave 0: x is the raw row, returns the blended value.  No stop among the
+        // candidates of this wave: the row stays raw and is finished after the sweep (finish_flagged_rows) -- unless it is the first
+        // row of a zone, whose blended value is the state of the zone above: then the whole sweep is redone row by row
+        auto blend = [&](double x, int t) {
             const double x1 = lane_up1(x), x2 = lane_up1(x1);
             const bool stop = lane >= 1 && lane <= last_cand && !(fabs((x - x1) - (x1 - x2)) > 0.0001);
             const unsigned long long mk = __ballot(stop);
             const int kf = mk ? __ffsll((long long)mk) : 1;
-            notfound |= (mk == 0);
+            if (mk == 0) {
+                notfound = true;
+                if (N - 3 > 61 && lane == 0) {
+                    if (t == zbeg1 || t == zbeg2) s_flag[0] = 1;
+                    else { flag_row(s_nf, t); s_flag[2] = 1; }
+                }
+            }
             const double r0 = readlane_f64(x, 0), rk = readlane_f64(x, kf);
             const double w = blend_weight(mu, readlane_f64(prmu, kf));         // mu_m / mu_kf
             const double bl = blend_val(w, r0, rk);
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                         // (rare; stored here so that the rows are not updated conditionally: no copies at the join)
 #pragma unroll
                         for (int u = 0; u < TC; ++u) {
-                            const double xb_ = blend(v[u]);
+                            const double xb_ = blend(v[u], t0 - u);
                             if (valid) {
                                 const int so = (t0 - u) * RB;
                                 bstore(rIn, vo, so, xb_);
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     const int t = t0 - u;
                     const double Un = rec_step(U, Ec[u], cc[u]);
                     double x = Un;
-                    if (w0 && t >= 0) x = blend(tid == 0 ? Jc[u] : Un);
+                    if (w0 && t >= 0) x = blend(tid == 0 ? Jc[u] : Un, t);
                     v[u] = x;
                     const bool zone_start = t == zbeg1 || t == zbeg2;   // blended row feeds the zone above
                     U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             // general body: zone boundaries, and the last chunk (row 0 feeds the convergence test)
             if (q < NQ) { chunk(std::true_type{}, M1{}); ++q; }
         }
-        if (w0 && notfound && lane == 0) s_flag[N - 3 <= 61 ? 1 : 0] = 1;
+        if (w0 && notfound && lane == 0 && N - 3 <= 61) s_flag[1] = 1;     // every candidate was in this wave: IndexError
     }
     }   // computing waves
     stamp(4);
@@ -589,8 +599,19 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         }
         return;
     }
+    if (!s_flag[0] && s_flag[2]) {
+        // rows whose search went past the lanes of wave 0: finished one by one (the ring is free by now)
+        if (finish_flagged_rows<ACC, SAVED>(s_nf, L, N, RB, g.mu, rIn, rI, rS, ring, rup_v, rup_i)) {
+            if (tid == 0) {                                             // the reference raises IndexError (spec:404)
+                a.cv.status[b] = SOSRT_COL_INDEXERROR;
+                if (ACC) { a.cv.active[b] = 0; a.cv.norders[b] = a.order; atomicSub(a.cv.nactive, 1); }
+            }
+            return;
+        }
+    }
     if (s_flag[0]) {
-        // A search of the upward sweep went past the lanes of wave 0 (spec:403-406 has no bound): redo that sweep here, row by
+        // The first row of a zone has no stop among the lanes of wave 0, and its blended value is the state of the zone above
+        // (spec:403-406 has no bound): redo that sweep here, row by
         // row, the row exchanged through LDS so that every direction can be a candidate.  Rare (never in the sweeps of the
         // bench), so written for size, not speed; it replaces the separate repair launch after every order.  The rows the
         // fast path stored are read back past the L1 to correct the running total: I += new - old.
@@ -669,7 +690,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 inline int ring_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
 inline size_t ring_extra_doubles(const Grid& g, int nt) {
     const int rs = g.N <= 128 ? 128 : 256, fc = kRingZones * ring_fixcap(g) * kFixMaxSrc;
-    return (size_t)(rs > fc ? rs : fc) + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 16 + 16;
+    return (size_t)(rs > fc ? rs : fc) + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 16 + 16 + (g.L + 63) / 64;
 }
 
 template <int PIECES>
@@ -705,6 +726,8 @@ bool transport_ring_ok(const Grid& g) {
     if (g.N % 2 || g.N < 4 || g.N > 256) return false;
     const int nwc = (g.N + 63) / 64, pieces = g.N <= 128 ? 1 : 2;
     const size_t slot_bytes = (size_t)3 * TC * 128 * pieces * sizeof(double);
+    // (the finishing of flagged rows works in the ring once the sweeps are over: it must fit two slots of the smallest form)
+    if (flagged_rows_work_doubles(g.L, g.N) * sizeof(double) > 2 * slot_bytes * 2 / 3) return false;
     return 2 * slot_bytes + ring_extra_doubles(g, (nwc + 4) * 64) * sizeof(double) <= kRingLdsBytes;
 }
 

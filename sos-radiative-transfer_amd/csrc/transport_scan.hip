@@ -56,7 +56,7 @@ template <bool SPLIT> struct ScanCfg {
 };
 constexpr int NLOAD = 4;                                   // loader waves
 constexpr int CR = 16;                                     // ring of carried values per lane group (> SW)
-constexpr int kScanScratch = 5 * 128;                      // doubles per column of the split form's exchange: 4 test rows + surface row
+constexpr int kScanScratch = 5 * 128 + 8;                  // doubles per column of the split form's exchange: 4 test rows + surface row + 16 words of flagged rows
 constexpr size_t kScanLdsBytes = 152 * 1024;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value arrives within a few thousand polls)
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     int* s_flagq = reinterpret_cast<int*>(s_xw + (size_t)ncw * 2 * TC * 16);
     int* s_landed = s_flagq + nwc * CR;
     int* s_taken = s_landed + NST;
-    __shared__ int s_flag[3];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] internal
+    int* s_nf = s_taken + NST * nwc;                           // [(L + 31) / 32] rows whose mu -> 0+ search left the first lane group (finish_flagged_rows)
+    __shared__ int s_flag[4];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] internal, [3] some row is flagged in s_nf
     double* s_x = s_xw + (size_t)(loader ? 0 : wid) * 2 * TC * 16;
     double* s_xI = s_x + TC * 16;
     const int xb_dn = max(lane_last - 15, 0);
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             const FixTab& src = g.fix[dg->fixtab[zz]];
             for (int i = tid; i < fixcap * kFixMaxSrc; i += nt) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
         }
-        if (tid < 3) s_flag[tid] = 0;
-        for (int i = tid; i < nwc * CR + NST + NST * nwc; i += nt) s_flagq[i] = 0;
+        if (tid < 4) s_flag[tid] = 0;
+        for (int i = tid; i < nwc * CR + NST + NST * nwc + (L + 31) / 32; i += nt) s_flagq[i] = 0;
         const double* __restrict__ tau = a.tau + (size_t)b * L;
         for (int t = tid; t <= L; t += nt) s_hd[t] = (t == 0 || t == L) ? 0.0 : (tau[t] - tau[t - 1]) * 0.5;
         if (tid < 16) s_prmu[tid] = (tid > 0 && tid < N) ? 1.0 / g.mu[N + tid] : 0.0;
@@ -609,12 +610,21 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         const int last_cand = min(N - 3, 61);
         bool notfound = false;
         // spec:401-409 for one row held across the first lane group: x is the raw row, returns the blended value
-        auto blend = [&](double x) __attribute__((always_inline)) {
+        // (no stop among the candidates of this lane group: the row stays raw and is finished after the sweep,
+        // finish_flagged_rows -- unless it is the first row of a zone, whose blended value is the state of the zone above:
+        // then the whole sweep is redone row by row)
+        auto blend = [&](double x, int t) __attribute__((always_inline)) {
             const double x1 = lane_up1(x), x2 = lane_up1(x1);
             const bool stop = lane >= 1 && lane <= last_cand && !(fabs((x - x1) - (x1 - x2)) > 0.0001);
             const unsigned long long mk = __ballot(stop);
             const int kf = mk ? __ffsll((long long)mk) : 1;
-            notfound |= (mk == 0);
+            if (mk == 0) {
+                notfound = true;
+                if (N - 3 > 61 && lane == 0 && t >= 0) {
+                    if (t == zbeg1 || t == zbeg2) s_flag[0] = 1;
+                    else { flag_row(s_nf, t); s_flag[3] = 1; }
+                }
+            }
             const double r0 = readlane_f64(x, 0), rk = readlane_f64(x, kf);
             const double w = blend_weight(mu, readlane_f64(prmu, kf));         // mu_m / mu_kf
             const double bl = blend_val(w, r0, rk);
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         v[u] = Un;
                         const bool zone_start = t == zbeg1 || t == zbeg2;
                         double x = Un;
-                        if (zone_start && w0) x = blend(dir == 0 ? Jc[u] : Un);
+                        if (zone_start && w0) x = blend(dir == 0 ? Jc[u] : Un, t);
                         U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
                     }
                     if (j + 1 < NCH) publish(NCH + j + 1, U);
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                     } else {
 #pragma unroll
                         for (int u = 0; u < TC; ++u) {
-                            const double xb_ = blend(v[u]);
+                            const double xb_ = blend(v[u], t0 - u);
                             if (valid && (!SP || t0 - u >= 0)) {
                                 const int so = (t0 - u) * RB;
                                 bstore(rIn, vo, so, xb_);
@@ -763,7 +773,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                     const int t = t0 - u;
                     const double Un = rec_step(U, Ec[u], cc[u]);
                     double x = Un;
-                    if (w0 && t >= 0) x = blend(dir == 0 ? Jc[u] : Un);
+                    if (w0 && t >= 0) x = blend(dir == 0 ? Jc[u] : Un, t);
                     v[u] = x;
                     const bool zone_start = t == zbeg1 || t == zbeg2;   // blended row feeds the zone above
                     U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
@@ -803,7 +813,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             else if (!w0) chunk(std::false_type{}, M0{}, j);
             else chunk(std::false_type{}, M1{}, j);
         }
-        if (w0 && notfound && lane == 0) s_flag[N - 3 <= 61 ? 1 : 0] = 1;
+        if (w0 && notfound && lane == 0 && N - 3 <= 61) s_flag[1] = 1;     // every candidate was in this lane group: IndexError
     }
     stamp(4);
     __syncthreads();
@@ -827,6 +837,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         // write-through in the first place (round 2 left them dirty in its L2: part 0 arriving last read stale rows).
         double* gs = a.scan_scratch + (size_t)b * kScanScratch;            // [4 test rows + surface row][128]
         int* sync = a.scan_sync + 2 * b;                                   // {arrivals, flags}
+        int* gnf = reinterpret_cast<int*>(gs + 5 * 128);                   // [16] bit mask of the flagged rows
         __shared__ int s_last;
         if (wid == 0) {                                                    // (lanes = this workgroup's directions)
             if (valid_dn) {
@@ -838,25 +849,28 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                 __hip_atomic_store(gs + 2 * 128 + dir, s_conv[2 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(gs + 3 * 128 + dir, s_conv[3 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            const int f = (s_flag[0] ? 1 : 0) | (s_flag[1] ? 2 : 0) | (s_flag[2] ? 4 : 0);
+            const int f = (s_flag[0] ? 1 : 0) | (s_flag[1] ? 2 : 0) | (s_flag[2] ? 4 : 0) | (s_flag[3] ? 8 : 0);
+            if (s_flag[3] && lane < (L + 31) / 32)                         // (part 0 only: it holds the mu -> 0+ lanes) the flagged rows
+                __hip_atomic_store(gnf + lane, s_nf[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (f && lane == 0) __hip_atomic_fetch_or(sync + 1, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // acknowledged: the words are where the other workgroup reads them
         }
         // part 1's write-through field rows of the upward sweep (see the stores): acknowledged by every wave before the arrival
         if (part == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (part 0 is the only one that can raise the flag; it writes its own rows back with a fence, once, in that rare case)
-        if (s_flag[0]) __atomic_thread_fence(__ATOMIC_RELEASE);           // (uniform) the redo will read this half's field rows
+        if (s_flag[0] || s_flag[3]) __atomic_thread_fence(__ATOMIC_RELEASE);   // (uniform) the redo / the finishing will read this half's field rows
         __syncthreads();
         if (tid == 0) s_last = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
         __syncthreads();
         if (!s_last) return;
         if (tid == 0) {
             const int f = __hip_atomic_exchange(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_flag[0] = f & 1; s_flag[1] = (f >> 1) & 1; s_flag[2] = (f >> 2) & 1;
+            s_flag[0] = f & 1; s_flag[1] = (f >> 1) & 1; s_flag[2] = (f >> 2) & 1; s_flag[3] = (f >> 3) & 1;
             __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next order
         }
         __syncthreads();
-        if (s_flag[0]) __atomic_thread_fence(__ATOMIC_ACQUIRE);           // (uniform, rare) the other half's field rows
+        if (s_flag[0] || s_flag[3]) __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (uniform, rare) the other half's field rows
+        if (s_flag[3] && tid < (L + 31) / 32) s_nf[tid] = __hip_atomic_load(gnf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < N; i += blockDim.x) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) s_conv[k * ND + i] = __hip_atomic_load(gs + k * 128 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -882,8 +896,20 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     const bool act = tid < N;
     double rup_v = act ? s_conv[2 * ND + tid] : 0.0, rup_i = act ? s_conv[3 * ND + tid] : 1.0;
     const double rdn_v = act ? s_conv[0 * ND + tid] : 0.0, rdn_i = act ? s_conv[1 * ND + tid] : 1.0;
+    if (!s_flag[0] && s_flag[3]) {
+        // rows whose search went past the lanes of the first lane group: finished one by one (the stages are free by now)
+        __syncthreads();
+        if (finish_flagged_rows<ACC, SAVED>(s_nf, L, N, RB, g.mu, rIn, rI, rS, s_stage, rup_v, rup_i)) {
+            if (tid == 0) {                                             // the reference raises IndexError (spec:404)
+                a.cv.status[b] = SOSRT_COL_INDEXERROR;
+                if (ACC) { a.cv.active[b] = 0; a.cv.norders[b] = a.order; atomicSub(a.cv.nactive, 1); }
+            }
+            return;
+        }
+    }
     if (s_flag[0]) {
-        // A search of the upward sweep went past the lanes of the first lane group (spec:403-406 has no bound): redo that
+        // The first row of a zone has no stop among the lanes of the first lane group, and its blended value is the state of
+        // the zone above (spec:403-406 has no bound): redo that
         // sweep here, row by row, the row exchanged through LDS so that every direction can be a candidate (as the ring
         // kernel does; rare, written for size).  The rows stored above are read back past the L1 to correct the running
         // total: I += new - old.
@@ -966,7 +992,7 @@ inline size_t scan_lds_bytes(const Grid& g) {
     const int nwc = SPLIT ? 1 : (g.N + 63) / 64, ncw = nwc * C::SW, nwaves = ncw + NLOAD, ND = (g.N + 63) / 64 * 64;
     const size_t doubles = (size_t)C::NST * C::STAGE + (size_t)nwc * CR * 64 + ND + (size_t)kRingZones * scan_fixcap(g) * kFixMaxSrc + nwaves + 2 +
                            g.L + 1 + (size_t)g.nsmall * g.L + 16 + 4 * ND + (size_t)ncw * 2 * TC * 16;
-    return doubles * sizeof(double) + ((size_t)(nwc * CR + C::NST + C::NST * nwc) * sizeof(int) + 7) / 8 * 8;
+    return doubles * sizeof(double) + ((size_t)(nwc * CR + C::NST + C::NST * nwc + (g.L + 31) / 32) * sizeof(int) + 7) / 8 * 8;
 }
 
 template <bool SPLIT>

@@ -108,6 +108,87 @@ __device__ __forceinline__ double blend_val(double w, double r0, double rk) {
 //   In_limit:113-141 as a linear map: acc + c x
 __device__ __forceinline__ double fix_acc(double c, double x, double acc) { return __builtin_fma(c, x, acc); }
 
+// ---- rows of the upward sweep whose mu -> 0+ search leaves the first wave ------------------------------------------------
+// spec:403-406 has no bound: `while |second difference| > 1e-4: idx++`.  The sweeps test the candidates that fit the first
+// wave of a row (lanes 1 .. 61); a row with no stop there is left RAW in memory (nothing blended: kf = 1) and flagged in an LDS
+// bit mask, and is finished here after the sweep, on its own: the recurrence does not depend on the blend (only the first row of
+// a zone hands its BLENDED value to the zone above, SURVEY H5 -- such a row takes the full row-by-row redo instead), so what
+// remains for a flagged row is the search over all N directions, the blend of the directions below the stop and the correction
+// of the running total, I += new - old.  Flagged rows go in batches of kNfBatch: their loads are issued together, then three
+// barriers per batch.  (Round 2 redid the whole sweep row by row for any such row, 3 us per row: 620 us per launch for the EVA
+// sweep, where 3 of 512 columns have a handful of such rows in the second order.)
+constexpr int kNfBatch = 8;
+// LDS doubles of the work area: kNfBatch rows of N + 2, the list of flagged rows, the stops, the count
+__host__ __device__ inline size_t flagged_rows_work_doubles(int L, int N) { return (size_t)kNfBatch * (N + 2) + (L + kNfBatch + 2 + 1) / 2 + 1; }
+__device__ __forceinline__ void flag_row(int* s_nf, int t) { atomicOr(&s_nf[t >> 5], 1 << (t & 31)); }
+// All threads of the workgroup call it; thread tid < N is upward direction N + tid.  Returns true if some row has no stop at all
+// (the reference raises IndexError, spec:404).
+template <bool ACC, bool SAVED>
+__device__ bool finish_flagged_rows(const int* s_nf, int L, int N, int RB, const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rIn,
+                                    __amdgpu_buffer_rsrc_t rI, __amdgpu_buffer_rsrc_t rS, double* s_work, double& rup_v, double& rup_i) {
+    const int tid = threadIdx.x, NP = N + 2;
+    double* s_rows = s_work;
+    int* s_list = reinterpret_cast<int*>(s_work + kNfBatch * NP);
+    int* s_kf = s_list + L;
+    int* s_cnt = s_kf + kNfBatch;
+    if (tid == 0) {
+        int c = 0;
+        for (int t = L - 1; t >= 0; --t)
+            if ((s_nf[t >> 5] >> (t & 31)) & 1) s_list[c++] = t;
+        *s_cnt = c;
+    }
+    __syncthreads();
+    const int cnt = *s_cnt;
+    const bool act = tid < N, tr = act && tid > 0;
+    const int j = act ? tid : 0;
+    const double mu = tr ? gmu[N + j] : 1.0;
+    const int vo = (N + j) * 8;
+    bool missing = false;
+    for (int c0 = 0; c0 < cnt; c0 += kNfBatch) {
+        const int nb = min(kNfBatch, cnt - c0);
+        double xo[kNfBatch], Io[kNfBatch];
+#pragma unroll
+        for (int i = 0; i < kNfBatch; ++i) {                    // the rows as the sweep left them, past the L1
+            const int t = s_list[c0 + min(i, nb - 1)];
+            xo[i] = bload_glc(rIn, vo, t * RB);
+            Io[i] = ACC ? bload_glc(rI, vo, t * RB) : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < kNfBatch; ++i)
+            if (act) s_rows[i * NP + j] = xo[i];
+        if (tid < kNfBatch) s_kf[tid] = 1 << 30;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kNfBatch; ++i) {
+            const double* r = s_rows + i * NP;
+            if (i < nb && act && j >= 1 && j <= N - 3 && !(fabs((r[j] - r[j + 1]) - (r[j + 1] - r[j + 2])) > 0.0001)) atomicMin(&s_kf[i], j);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kNfBatch; ++i) {
+            if (i >= nb) continue;
+            const double* r = s_rows + i * NP;
+            const int ks = s_kf[i];
+            missing |= ks == (1 << 30);
+            const int kf = ks == (1 << 30) ? 1 : ks + 1;
+            const int t = s_list[c0 + i];
+            if (tr && tid < kf) {                               // spec:407-409
+                const double x = blend_val(blend_weight(mu, 1.0 / gmu[N + kf]), r[0], r[kf]);
+                bstore(rIn, vo, t * RB, x);
+                double It = 0;
+                if (ACC) {
+                    It = Io[i] + (x - xo[i]);
+                    bstore(rI, vo, t * RB, It);
+                }
+                if (SAVED) bstore(rS, vo, t * RB, x);
+                if (t == 0) { rup_v = x; rup_i = It; }
+            }
+        }
+        __syncthreads();
+    }
+    return missing;
+}
+
 // Python's max() over a row (see block_pymax in kernels.hip); first_tid holds element 0.
 __device__ double block_pymax_(double x, bool valid, double* s_red, int first_tid) {
     const int tid = threadIdx.x, nw = blockDim.x >> 6;

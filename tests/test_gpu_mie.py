@@ -117,6 +117,53 @@ def test_c5_wildfire_subset_l400_n256():
     _solve_vs_oracle("wildfire", WILDFIRE, 400, 256, cols, [0, b_scn, 63], "C5 subset")
 
 
+def test_rows_whose_search_leaves_the_first_wave_are_finished_one_by_one(monkeypatch):
+    """Three columns of the EVA headline sweep (mu0 = 0.2, bright ground) have, in the second order, a handful of rows whose
+    upward mu -> 0+ search (spec:403-406) runs past lane 61 -- not the first row of a zone.  Round 2 redid the whole sweep row
+    by row for them (620 us on the 512-column launch); now such rows are flagged and finished one by one after the sweep.
+    Ring kernel, chunk-parallel kernel with one and with two workgroups per column: the same bits, and the oracle's field."""
+    L, N = 200, 128
+    tg, rg = np.geomspace(0.01, 1.0, 8), np.linspace(0.0, 0.8, 8)          # the axes of the headline sweep (bench.build_sweep)
+    cols = [(0.2, tg[3], rg[7]), (0.2, tg[4], rg[6]), (0.2, tg[4], rg[7]), (0.5, 0.12, 0.15)]       # its columns 31, 38, 39
+    m0, ta, rh = (np.array(x, dtype=np.float64) for x in zip(*cols))
+    P_atm, P_aer, p0 = _oracle_inputs("eva", N, np.unique(m0))
+    P0a = np.stack([p0[float(m)][0] for m in m0]); P0r = np.stack([p0[float(m)][1] for m in m0])
+    kw = dict(tauStar_atm=0.124, alb_aer=0.97, nb_layers=L, nb_angles=N, z_up=25, z_down=17, max_orders=200,
+              P_atm=P_atm, P_aer=P_aer, P0_atm=P0a, P0_aer=P0r)
+    out = {}
+    for tag, env in (("ring", dict(SOSRT_TRANSPORT="ring")), ("scan2", dict(SOSRT_TRANSPORT="scan")),
+                     ("scan1", dict(SOSRT_TRANSPORT="scan", SOSRT_SCAN_SPLIT="0")), ("general", dict(SOSRT_TRANSPORT="general"))):
+        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                     # (part of the solver cache's key / read when the handle is created)
+        from sosrt import main as M
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+        out[tag] = SOS_Aer_batch(m0, ta, rh, **kw)
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    ring = out["ring"]
+    for tag in ("scan1", "scan2"):
+        assert np.array_equal(out[tag].n, ring.n) and np.array_equal(out[tag].I, ring.I), tag
+    iu, idn = inputs.slab_indices(120, 25, 17, L)
+    flagged = 0
+    for b, (a, t, g) in enumerate(cols):
+        col = O.make_column(a, 120, 25, 17, L, 0.124, t, g, 1.0, 0.97, N, P0a[b], P_atm, P0r[b], P_aer)
+        ref = O.solve_column(col, literal=False)
+        for tag in ("ring", "general"):
+            assert out[tag].n[b] == ref.n, (tag, b)
+            assert_close(out[tag].I[b], ref.I, RTOL, "%s column %d" % (tag, b))
+        # rows of the second order that are exactly linear in mu beyond lane 61: the long searches; none of them opens a zone
+        reach = np.argmax(np.abs(np.diff(ref.I_saved[1][:, N:], 2, axis=1)) > 1e-12, axis=1) + 1
+        rows = np.nonzero(reach > 61)[0]
+        assert iu not in rows and (idn + 1) not in rows      # (the first rows of the zones, going up)
+        flagged += len(rows)
+    assert flagged >= 6
+
+
 def test_symmetric_and_full_contraction_agree_on_a_forward_peaked_matrix():
     """What the flip-symmetric form drops is the antisymmetric part of the folded matrices (sosrt.h, sosrt_set_contraction).
     The EVA matrix is the most forward-peaked input of the suite (p(1)/p(-1) = 117, max P = 59): the two forms of the

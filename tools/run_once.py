@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One solve of the bench sweep (for rocprofv3 runs): python3 tools/run_once.py [columns] [solves] [angles]"""
+"""One solve of the bench sweep (for rocprofv3 runs): python3 tools/run_once.py [columns] [solves] [angles]
+(environment: AEROSOL = eva | wildfire | hg, default eva as in bench.py; LAYERS, default 200)"""
 import os
 import sys
 
@@ -15,7 +16,7 @@ from sosrt.solver import Solver
 cols = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 solves = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 NANG = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-w = bench.build_sweep(cols, 200, NANG, 0, 1)
+w = bench.build_sweep(cols, int(os.environ.get("LAYERS", "200")), NANG, 0, 1, aerosol=os.environ.get("AEROSOL", "eva"))
 B, L, N = w["B"], w["L"], w["N"]
 dev = torch.device("cuda", 0)
 s = Solver(L, N, max_batch=B, max_orders=256)
