@@ -642,7 +642,7 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
             HIPCHK(hipMemcpy(h->d_small, h->plan.small_lanes.data(), h->g.nsmall * sizeof(int), hipMemcpyHostToDevice));
         h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
         h->scan_ok = h->ring_ok && transport_scan_ok(h->g);
-        h->scan_split_ok = h->scan_ok && transport_scan_split_ok(h->g);
+        h->scan_split_ok = h->ring_ok && transport_scan_split_ok(h->g);      // (N in (128, 256]: the chunk-parallel kernel has this form only)
     }
     return 0;
 }
@@ -1138,13 +1138,15 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 // need not stage those rows either
                 // the kernel of this launch: the chunk-parallel one while few columns are live (same bits as the ring kernel)
                 const int cols_now = tail_cols > 0 ? tail_cols : q.nb;
-                const int fast_mode = (h->scan_ok && (h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols))) ? 4 : ring_mode;
+                // chunk-parallel kernel: a column on ceil(N / 64) CUs (two at N = 128, four at N = 256) while that many
+                // workgroups per live column fit the device at once (the reflection must stay inside a part)
+                const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= h->cu_count &&
+                                       (h->surface == SOSRT_SURFACE_SPECULAR || h->surface == SOSRT_SURFACE_NONE);
+                const bool want_scan = h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols);
+                const int fast_mode = (ring_mode == 3 && want_scan && (h->scan_ok || can_split)) ? 4 : ring_mode;
                 Grid gt = g;
                 if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
-                // chunk-parallel kernel: a column on two CUs while at most half as many columns are live as there are CUs (the
-                // reflection must stay inside a half)
-                const int split = (fast_mode == 4 && h->scan_split && h->scan_split_ok && 2 * cols_now <= h->cu_count &&
-                                   (h->surface == SOSRT_SURFACE_SPECULAR || h->surface == SOSRT_SURFACE_NONE)) ? 1 : 0;
+                const int split = (fast_mode == 4 && can_split) ? 1 : 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0, split,
                                  h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(), h->d_scan_sync + 2 * q.b0,

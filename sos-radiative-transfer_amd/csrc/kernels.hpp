@@ -134,6 +134,7 @@ void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int
 // transport_scan.hip: the chunks of a sweep dealt to several waves (chunk-local recurrence + carried values)
 bool transport_scan_ok(const Grid& g);
 bool transport_scan_split_ok(const Grid& g);
+int transport_scan_parts(const Grid& g);                       // workgroups per column of the split form: ceil(N / 64)
 size_t transport_scan_scratch_doubles();                       // per column
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a);
 extern int g_ring_slots, g_ring_debug;                        // tuning (SOSRT_RING_SLOTS)

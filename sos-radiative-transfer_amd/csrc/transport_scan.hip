@@ -56,7 +56,8 @@ template <bool SPLIT> struct ScanCfg {
 };
 constexpr int NLOAD = 4;                                   // loader waves
 constexpr int CR = 16;                                     // ring of carried values per lane group (> SW)
-constexpr int kScanScratch = 5 * 128 + 8;                  // doubles per column of the split form's exchange: 4 test rows + surface row + 16 words of flagged rows
+constexpr int kScanDirs = 256;                             // most directions per hemisphere of the split form
+constexpr int kScanScratch = 5 * kScanDirs + 8;            // doubles per column of the split form's exchange: 4 test rows + surface row + 16 words of flagged rows
 constexpr size_t kScanLdsBytes = 152 * 1024;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value arrives within a few thousand polls)
@@ -64,8 +65,10 @@ constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value a
 template <bool ACC, bool SAVED, bool SPLIT>
 __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fixcap) {
     constexpr int SW = ScanCfg<SPLIT>::SW, NST = ScanCfg<SPLIT>::NST, SROW = ScanCfg<SPLIT>::SROW, STAGE = ScanCfg<SPLIT>::STAGE;
-    const int part = SPLIT ? (int)(blockIdx.x & 1) : 0;
-    int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    // SPLIT: ceil(N / 64) workgroups per column (two at N = 128, four at N = 256), part p = blockIdx.x mod that
+    const int nparts = SPLIT ? (a.g.N + 63) >> 6 : 1;
+    const int part = SPLIT ? (int)(blockIdx.x % nparts) : 0;
+    int b = SPLIT ? (int)(blockIdx.x / nparts) : (int)blockIdx.x;
     if (ACC && a.live > 0) {
         b = a.live_list[b];
         if (b < 0) return;                          // fewer live columns than the host's (lagging) count
@@ -82,11 +85,13 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     const int ncw = nwc * SW;                                  // computing waves; the NLOAD loader waves follow
     const bool loader = wid >= ncw;
     const int lg = wid % nwc, grp = loader ? wid - ncw : wid / nwc;   // this wave: 64 directions, chunks grp, grp + SW, ... (loaders: grp, grp + NLOAD, ...)
-    // downward direction dir_dn, then upward direction N + dir; split: part 0 = upward 0..63 and their mirror images N-64..N-1
+    // downward direction dir_dn, then upward direction N + dir; split: part p = upward 64p .. 64p+63 and their mirror images,
+    // the downward directions N-64(p+1) .. N-64p-1 (the last part of an N that is no multiple of 64: from 0)
     const int dir = SPLIT ? part * 64 + lane : lg * 64 + lane;
-    const int dir_dn = SPLIT ? (part == 0 ? N - 64 + lane : lane) : dir;
+    const int dn0 = SPLIT ? max(N - 64 * (part + 1), 0) : 0;   // first downward direction of this part
+    const int dir_dn = SPLIT ? dn0 + lane : dir;
     const bool valid = dir < N;
-    const bool valid_dn = SPLIT ? (part == 0 || lane < N - 64) : valid;
+    const bool valid_dn = SPLIT ? dir_dn < N - 64 * part : valid;
     const int dirc = valid ? dir : N - 1;
     const int dirc_dn = valid_dn ? dir_dn : 0;
     const bool w0 = !loader && (SPLIT ? part == 0 : lg == 0);                    // holds the mu -> 0+ lanes
@@ -163,26 +168,6 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             }
     }
 
-    // ---- per-column tables ----
-    {
-        const int nt = blockDim.x;
-        for (int zz = 0; zz < kRingZones; ++zz) {
-            const FixTab& src = g.fix[dg->fixtab[zz]];
-            for (int i = tid; i < fixcap * kFixMaxSrc; i += nt) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
-        }
-        if (tid < 4) s_flag[tid] = 0;
-        for (int i = tid; i < nwc * CR + NST + NST * nwc + (L + 31) / 32; i += nt) s_flagq[i] = 0;
-        const double* __restrict__ tau = a.tau + (size_t)b * L;
-        for (int t = tid; t <= L; t += nt) s_hd[t] = (t == 0 || t == L) ? 0.0 : (tau[t] - tau[t - 1]) * 0.5;
-        if (tid < 16) s_prmu[tid] = (tid > 0 && tid < N) ? 1.0 / g.mu[N + tid] : 0.0;
-        const double* __restrict__ In0 = a.In + (size_t)b * L * D;
-        for (int i = tid; i < g.nsmall * L; i += nt) {
-            const int k = i / L, t = i - k * L;
-            s_S[i] = In0[(size_t)t * D + g.small_lanes[k]];
-        }
-    }
-    __syncthreads();
-    stamp(1);
 
     // The value carried into chunk q of this lane group, published by the wave of chunk q - 1.  Plain LDS accesses in
     // program order, no atomics: the LDS serves a wave's instructions in order, so a flag written after the value is seen
@@ -251,7 +236,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         double* dst = s_stage + (size_t)(gq % NST) * STAGE;
         const int t0 = up ? L - 1 - q * TC : q * TC;
         // byte offset of this workgroup's directions in a row: the half row (1 KiB pieces), or -- split -- its 64 directions (512 B)
-        const int half = SPLIT ? (up ? N * 8 + part * 512 : (part == 0 ? (N - 64) * 8 : 0)) : (up ? N * 8 : 0);
+        const int half = SPLIT ? (up ? N * 8 + part * 512 : dn0 * 8) : (up ? N * 8 : 0);
         const int vo = lane * 16;
         if (!SPLIT || lane < 32) {
 #pragma unroll
@@ -268,11 +253,11 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     // Loader `grp` carries the chunks g = grp, grp + SW, ... of both sweeps.  Chunk g goes into stage g mod NST once every
     // lane group has taken chunk g - NST out of it: with NST > SW a residue's next chunk is requested before its current
     // one is even started.
-    auto load_chunks = [&](int g0, int g1) __attribute__((always_inline)) {
+    auto load_chunks = [&](int g0, int g1, bool first_issued) __attribute__((always_inline)) {
         for (int gq = g0; gq < g1; gq += NLOAD) {
             if (gq >= NST)
                 for (int i = 0; i < nwc; ++i) spin(l_taken + (gq % NST) * nwc + i, gq - NST + 1);
-            issue(gq);
+            if (!(first_issued && gq == g0)) issue(gq);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) l_landed[gq % NST] = gq + 1;
         }
@@ -288,10 +273,34 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     const double* xrow = s_x + uT * 16;
     double Bv = 0;
 
+    // The loaders put their first chunk in flight before the per-column tables are filled: nothing of it depends on them, and
+    // the two memory latencies (tables, first stage) overlap instead of adding up at the head of every launch.
+    if (loader && g_next < g_seam) issue(g_next);
+    // ---- per-column tables ----
+    {
+        const int nt = blockDim.x;
+        for (int zz = 0; zz < kRingZones; ++zz) {
+            const FixTab& src = g.fix[dg->fixtab[zz]];
+            for (int i = tid; i < fixcap * kFixMaxSrc; i += nt) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
+        }
+        if (tid < 4) s_flag[tid] = 0;
+        for (int i = tid; i < nwc * CR + NST + NST * nwc + (L + 31) / 32; i += nt) s_flagq[i] = 0;
+        const double* __restrict__ tau = a.tau + (size_t)b * L;
+        for (int t = tid; t <= L; t += nt) s_hd[t] = (t == 0 || t == L) ? 0.0 : (tau[t] - tau[t - 1]) * 0.5;
+        if (tid < 16) s_prmu[tid] = (tid > 0 && tid < N) ? 1.0 / g.mu[N + tid] : 0.0;
+        const double* __restrict__ In0 = a.In + (size_t)b * L * D;
+        for (int i = tid; i < g.nsmall * L; i += nt) {
+            const int k = i / L, t = i - k * L;
+            s_S[i] = In0[(size_t)t * D + g.small_lanes[k]];
+        }
+    }
+    __syncthreads();
+    stamp(1);
+
     // =============================== downward ===============================
     if (loader) {
         // the chunks of the downward sweep and, across the seam, the first ones of the upward sweep
-        load_chunks(g_next, g_seam);
+        load_chunks(g_next, g_seam, true);
         while (g_next < g_seam) g_next += NLOAD;
     } else {
         const int m = dirc_dn;
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 
     // =============================== upward ===============================
     if (loader) {
-        load_chunks(g_next, 2 * NCH);
+        load_chunks(g_next, 2 * NCH, false);
     } else {
         const int mj = N + dirc;
         const int vo = mj * 8;
@@ -835,19 +844,19 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         // workgroup runs it, those rows must be in memory by then: part 0 (the only one that can ask for the redo) writes
         // its L2 back with a release fence in that rare case; part 1, which cannot know, stores its upward rows
         // write-through in the first place (round 2 left them dirty in its L2: part 0 arriving last read stale rows).
-        double* gs = a.scan_scratch + (size_t)b * kScanScratch;            // [4 test rows + surface row][128]
+        double* gs = a.scan_scratch + (size_t)b * kScanScratch;            // [4 test rows + surface row][kScanDirs]
         int* sync = a.scan_sync + 2 * b;                                   // {arrivals, flags}
-        int* gnf = reinterpret_cast<int*>(gs + 5 * 128);                   // [16] bit mask of the flagged rows
+        int* gnf = reinterpret_cast<int*>(gs + 5 * kScanDirs);             // [16] bit mask of the flagged rows
         __shared__ int s_last;
         if (wid == 0) {                                                    // (lanes = this workgroup's directions)
             if (valid_dn) {
-                __hip_atomic_store(gs + 0 * 128 + dir_dn, s_conv[0 * ND + dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gs + 1 * 128 + dir_dn, s_conv[1 * ND + dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gs + 4 * 128 + dir_dn, s_sfc[dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 0 * kScanDirs + dir_dn, s_conv[0 * ND + dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 1 * kScanDirs + dir_dn, s_conv[1 * ND + dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 4 * kScanDirs + dir_dn, s_sfc[dir_dn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (valid) {
-                __hip_atomic_store(gs + 2 * 128 + dir, s_conv[2 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gs + 3 * 128 + dir, s_conv[3 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 2 * kScanDirs + dir, s_conv[2 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 3 * kScanDirs + dir, s_conv[3 * ND + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const int f = (s_flag[0] ? 1 : 0) | (s_flag[1] ? 2 : 0) | (s_flag[2] ? 4 : 0) | (s_flag[3] ? 8 : 0);
             if (s_flag[3] && lane < (L + 31) / 32)                         // (part 0 only: it holds the mu -> 0+ lanes) the flagged rows
@@ -856,11 +865,11 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // acknowledged: the words are where the other workgroup reads them
         }
         // part 1's write-through field rows of the upward sweep (see the stores): acknowledged by every wave before the arrival
-        if (part == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (part != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (part 0 is the only one that can raise the flag; it writes its own rows back with a fence, once, in that rare case)
         if (s_flag[0] || s_flag[3]) __atomic_thread_fence(__ATOMIC_RELEASE);   // (uniform) the redo / the finishing will read this half's field rows
         __syncthreads();
-        if (tid == 0) s_last = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+        if (tid == 0) s_last = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nparts - 1;
         __syncthreads();
         if (!s_last) return;
         if (tid == 0) {
@@ -873,8 +882,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         if (s_flag[3] && tid < (L + 31) / 32) s_nf[tid] = __hip_atomic_load(gnf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < N; i += blockDim.x) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s_conv[k * ND + i] = __hip_atomic_load(gs + k * 128 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_sfc[i] = __hip_atomic_load(gs + 4 * 128 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 4; ++k) s_conv[k * ND + i] = __hip_atomic_load(gs + k * kScanDirs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_sfc[i] = __hip_atomic_load(gs + 4 * kScanDirs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -1030,16 +1039,20 @@ bool transport_scan_ok(const Grid& g) {
     if ((g.L + TC - 1) / TC > 64) return false;
     return scan_lds_bytes<false>(g) <= kScanLdsBytes;
 }
-// two workgroups per column: two lane groups to deal, whole 16-byte lanes in a group's 512 bytes
+// ceil(N / 64) workgroups per column: at least two lane groups to deal, whole 16-byte lanes in a group's 512 bytes, at most
+// kScanDirs directions per hemisphere (the exchange rows), at most 64 chunks per sweep.  N in (128, 256] has this form only.
 bool transport_scan_split_ok(const Grid& g) {
-    return transport_scan_ok(g) && g.N > 64 && g.N % 2 == 0 && scan_lds_bytes<true>(g) <= kScanLdsBytes;
+    if (g.N % 2 || g.N <= 64 || g.N > kScanDirs) return false;
+    if ((g.L + TC - 1) / TC > 64) return false;
+    return scan_lds_bytes<true>(g) <= kScanLdsBytes;
 }
+int transport_scan_parts(const Grid& g) { return (g.N + 63) / 64; }
 size_t transport_scan_scratch_doubles() { return kScanScratch; }
 
 // a.scan_split: two workgroups per column (the grid is then twice the columns; specular surface or none; a.scan_scratch /
 // a.scan_sync: kScanScratch doubles and two zeroed ints per column of the batch)
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a) {
-    if (a.scan_split && a.accumulate) launch_scan_t<true>(s, dim3(2 * grid.x), a);
+    if (a.scan_split && a.accumulate) launch_scan_t<true>(s, dim3(transport_scan_parts(a.g) * grid.x), a);
     else launch_scan_t<false>(s, grid, a);
 }
 

@@ -384,11 +384,12 @@ def test_transport_kernel_follows_the_live_count_with_the_same_bits(monkeypatch)
     fresh()
 
 
-@pytest.mark.parametrize("L,N", [(3, 8), (4, 64), (5, 128), (8, 32), (9, 128), (17, 100), (33, 64), (65, 128)])
+@pytest.mark.parametrize("L,N", [(3, 8), (4, 64), (5, 128), (8, 32), (9, 128), (17, 100), (33, 64), (65, 128),
+                                 (40, 256), (26, 192), (21, 200), (200, 256)])
 def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
     """The chunk-parallel kernel for every order on columns of fewer chunks than it has waves, ragged last chunks, one or
-    two lane groups, one or two workgroups per column, against the ring kernel: same order counts and statuses (IndexError,
-    order budget), same bits."""
+    two lane groups, one, two, three or four workgroups per column (N = 192, 200 -- a last part of 8 lanes -- and 256: the
+    split form only), against the ring kernel: same order counts and statuses (IndexError, order budget), same bits."""
     from sosrt import main as M
     rng = np.random.default_rng(100 * L + N)
     B = 5
