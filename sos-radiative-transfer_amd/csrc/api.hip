@@ -1122,7 +1122,10 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             const size_t fo = (size_t)q.b0 * LD;
             // this launch also publishes the group's live count after order n-1
             // (the float contraction has the dense tiling only: no live list for the transport either)
-            const int tail_cols = (h->contraction != SOSRT_CONTRACT_F32 && h->simple_zones && q.known < q.nb && q.known <= h->gemm_tail_cols) ? q.known : 0;
+            // (the tilings over the live columns whenever some column has converged -- and for a small batch from the start:
+            // their 32-row tiles put a few columns on more CUs than the dense tiling's 64-row tiles; same bits either way)
+            const int tail_cols = (h->contraction != SOSRT_CONTRACT_F32 && h->simple_zones && q.known <= h->gemm_tail_cols &&
+                                   (q.known < q.nb || q.nb <= h->gemm_small_cols)) ? q.known : 0;
             run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway

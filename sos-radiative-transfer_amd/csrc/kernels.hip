@@ -167,8 +167,14 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
     // blockIdx.y = 0: the downward half of the field, 1: the upward half and the loop test.  The upward
     // half needs the downward radiance at the surface (spec:211); it evaluates that one row itself (the
     // same closed form, one row per zone) instead of waiting for the other workgroup.
+    // blockIdx.z = row block: the rows of a zone are independent closed forms once the zone's boundary row is known, and
+    // that row is itself a closed form (one row per zone above it), so a workgroup takes the rows t = blockIdx.z mod gridDim.z
+    // and evaluates the boundary rows for itself.  A lone column is then spread over 2 x gridDim.z workgroups instead of two
+    // (its fp64 exponentials are a latency chain: 94 us for one column with two), and a full batch keeps more waves per SIMD
+    // to hide them behind.
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool up_half = blockIdx.y == 1;
+    const int blk = blockIdx.z, nblk = gridDim.z;
     const int L = g.L, N = g.N, D = g.D;
     extern __shared__ double sm[];
     double* s_tau = sm;                 // [L]
@@ -200,6 +206,9 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
     }
     __syncthreads();
     constexpr int FU = 4;    // rows of a zone are independent: FU of them are evaluated together
+    // first row >= r of this block (rows t with t mod nblk == blk)
+    auto first_from = [&](int r) { return r + ((blk - r % nblk) + nblk) % nblk; };
+    auto last_upto = [&](int r) { return r - ((r % nblk - blk) + nblk) % nblk; };
 
     // ---- downward, m = tid ----
     {
@@ -220,33 +229,32 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             const double t_bs = z ? s_tau[d.r0[z]] : 0.0;
             const double e_bd = exp(-t_bd / mu0), e_bs = exp(-(T - t_bs) / mu0);
             const int r1 = d.r1[z];
-            const int r0 = up_half ? r1 : d.r0[z];          // the upward half only needs the last row of each zone
-            for (int tb = r0; tb <= r1; tb += FU) {
-                double v[FU];
+            auto row = [&](int t) {
+                const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
+                const double x = exp((tt - t_bd) / mu), xs = exp((tt - t_bs) / mu);
+                const double before = z ? Ib * x : 0.0;
+                const double direct = near ? q * F0 * e0 * (tt - t_bd) / mu0 : gd * q * F0 * (e0 - e_bd * x);
+                const double surf = gs * qm * R * (eT - e_bs * xs);
+                const double vnode = gd * q * F0 * e0 + gs * qm * R * eT;
+                return node ? vnode : before + direct + surf;
+            };
+            if (!up_half) {                                  // (the upward half only needs the last row of each zone)
+                for (int tb = first_from(d.r0[z]); tb <= r1; tb += FU * nblk) {
+                    double v[FU];
 #pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int t = min(tb + u, r1);
-                    const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
-                    const double x = exp((tt - t_bd) / mu), xs = exp((tt - t_bs) / mu);
-                    const double before = z ? Ib * x : 0.0;
-                    const double direct = near ? q * F0 * e0 * (tt - t_bd) / mu0 : gd * q * F0 * (e0 - e_bd * x);
-                    const double surf = gs * qm * R * (eT - e_bs * xs);
-                    const double vnode = gd * q * F0 * e0 + gs * qm * R * eT;
-                    v[u] = node ? vnode : before + direct + surf;
-                }
+                    for (int u = 0; u < FU; ++u) v[u] = row(min(tb + u * nblk, r1));
 #pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int t = tb + u;
-                    if (t <= r1) {
-                        if (valid && !up_half) {
+                    for (int u = 0; u < FU; ++u) {
+                        const int t = tb + u * nblk;
+                        if (t <= r1 && valid) {
                             I1[(size_t)t * D + m] = v[u];
                             if (Iacc) Iacc[(size_t)t * D + m] = v[u];
                             if (sv) sv[(size_t)t * D + m] = v[u];
                         }
-                        vlast = v[u];
                     }
                 }
             }
+            vlast = row(r1);                                  // the zone's last row: boundary row of the next zone, surface row
             Ib = vlast;
         }
         s_sfc[tid] = vlast;                                   // I1[L-1][m]
@@ -275,37 +283,37 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             const double t_su = bottom ? T : s_tau[d.r1[z]];
             const double e_bu = exp(-t_bu / mu0), e_su = exp(-(T - t_su) / mu0);
             const int r0 = d.r0[z], r1 = d.r1[z];
-            for (int tb = r1; tb >= r0; tb -= FU) {
+            auto row = [&](int t) {
+                const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
+                const double yb = exp(-(t_bb - tt) / mu);
+                const double yu = bottom ? exp(-(t_bu - tt) / mu) : yb;      // (above the bottom zone t_bb = t_bu: the same exponential)
+                const double ys = exp(-(t_su - tt) / mu);
+                const double before = Bv * yb;
+                const double direct = gd * q * F0 * (e0 - e_bu * yu);
+                const double surf = near ? qm * R * eT * (t_su - tt) / mu0 : gs * qm * R * (eT - e_su * ys);
+                const double vnode = gd * q * F0 * e0 + gs * qm * R * eT;
+                return node ? vnode : before + direct + surf;
+            };
+            for (int tb = last_upto(r1); tb >= r0; tb -= FU * nblk) {
                 double v[FU];
 #pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int t = max(tb - u, r0);
-                    const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
-                    const double yb = exp(-(t_bb - tt) / mu), yu = exp(-(t_bu - tt) / mu), ys = exp(-(t_su - tt) / mu);
-                    const double before = Bv * yb;
-                    const double direct = gd * q * F0 * (e0 - e_bu * yu);
-                    const double surf = near ? qm * R * eT * (t_su - tt) / mu0 : gs * qm * R * (eT - e_su * ys);
-                    const double vnode = gd * q * F0 * e0 + gs * qm * R * eT;
-                    v[u] = node ? vnode : before + direct + surf;
-                }
+                for (int u = 0; u < FU; ++u) v[u] = row(max(tb - u * nblk, r0));
 #pragma unroll
                 for (int u = 0; u < FU; ++u) {
-                    const int t = tb - u;
-                    if (t >= r0) {
-                        if (valid) {
-                            I1[(size_t)t * D + m] = v[u];
-                            if (Iacc) Iacc[(size_t)t * D + m] = v[u];
-                            if (sv) sv[(size_t)t * D + m] = v[u];
-                        }
-                        vlast = v[u];
+                    const int t = tb - u * nblk;
+                    if (t >= r0 && valid) {
+                        I1[(size_t)t * D + m] = v[u];
+                        if (Iacc) Iacc[(size_t)t * D + m] = v[u];
+                        if (sv) sv[(size_t)t * D + m] = v[u];
                     }
                 }
             }
-            Bv = vlast;                                       // row r0 of this zone feeds the zone above
+            vlast = row(r0);                                  // row r0 of this zone feeds the zone above
+            Bv = vlast;
         }
         rup = 1.0 / vlast;                                    // I1[0][m]
     }
-    if (do_conv) {
+    if (do_conv && blk == 0) {
         const double a = block_pymax(rup, valid, s_red);
         const double bb = block_pymax(rdn, valid, s_red);
         const double r = outer_pymax(a, bb);
@@ -534,7 +542,12 @@ void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, 
                         Conv cv, int do_conv) {
     const int nt = round64(g.N);
     const size_t shm = (size_t)(3 * g.L + nt + nt / 64 + 4) * sizeof(double);
-    hipLaunchKernelGGL(k_first_order, dim3(B, 2), dim3(nt), shm, s, g, tau, P0a, P0r, desc, I1_out, I_out, saved,
+    // row blocks per half column: enough workgroups to give every SIMD several waves (the rows are chains of fp64
+    // exponentials), at least ~24 rows per block (each block also evaluates one boundary row per zone)
+    int nblk = (4096 + 2 * B - 1) / (2 * B);
+    nblk = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
+    while (nblk > 1 && g.L / nblk < 24) --nblk;
+    hipLaunchKernelGGL(k_first_order, dim3(B, 2, nblk), dim3(nt), shm, s, g, tau, P0a, P0r, desc, I1_out, I_out, saved,
                        saved_col_stride, cv, do_conv);
 }
 
