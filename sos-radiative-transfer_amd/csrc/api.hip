@@ -322,7 +322,7 @@ int ensure_matrices(sosrt_handle* h, hipStream_t s) {
 // Jn for every row of a column group (grp < 0: the whole batch) in one launch: plain rows against W_atm, slab rows
 // against the combined matrix of their coefficient pair (or W_atm and W_aer in two passes)
 void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0,
-                int grp = -1) {
+                int grp = -1, bool all_live = false) {
     const int g0 = grp < 0 ? 0 : grp, g1 = grp < 0 ? h->ngroups : grp + 1;
     const int pg = grp < 0 ? 0 : grp;
     hipStream_t s = group_stream(h, pg);
@@ -350,12 +350,19 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
         ga.nactive = h->d_nactive + pg; ga.need_small = h->d_nactive + sosrt_handle::kMaxGroups;
         ga.host_pub = h->h_pub + 8 * pg; ga.tag = pub_tag;
     }
+    // The dense tiling skips the tiles whose columns have all converged -- two barriers and a dependent load per tile.  When the
+    // host knows every column of the launch to be live (its count lags by one order: at most the columns that converged in the
+    // last order are multiplied once more, and the transport ignores them) the check is dropped: 160 -> 157 us per 512-column launch.
+    ga.check_tiles = all_live ? 0 : 1;
     if (ensure_matrices(h, s)) return;                 // (allocation failure: reported by the caller's hipGetLastError / next call)
     if (h->mix_groups > 0) {
         ga.Wmix = h->d_Wmix; ga.mix_group = h->d_mixgroup; ga.slab_tile_group = h->d_slabtilegroup + h->slab_off[g0] / 32;
     }
     if (use_sym(h)) {
         ga.sym = 1; ga.Ks = (h->g.N + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
+        // diagnostic (timing only; the results do not change: the extra chunks multiply zeros): SOSRT_GEMM_KS_MULT=2 doubles the
+        // chunks per tile at the same prologue / epilogue, which separates the two (tile time = P + chunks * C)
+        if (const char* ev = getenv("SOSRT_GEMM_KS_MULT")) { const int m = atoi(ev); if (m > 1 && ga.Ks * m <= h->g.Dp) ga.Ks *= m; }
         ga.Wa = h->d_Wa_s; ga.Wr = h->d_Wr_s;
         if (ga.Wmix) ga.Wmix = h->d_Wmix_s;
     }
@@ -471,8 +478,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_desc, mb))) return e;
             if ((e = dalloc(&h->d_rca, mb * L))) return e;
             if ((e = dalloc(&h->d_rcr, mb * L))) return e;
-            if ((e = dalloc(&h->d_slabrows, mb * L + 32 * (size_t)sosrt_handle::kMaxMixGroups * sosrt_handle::kMaxGroups))) return e;   // + padding
-            if ((e = dalloc(&h->d_slabtilegroup, mb * L / 32 + sosrt_handle::kMaxMixGroups * sosrt_handle::kMaxGroups + 1))) return e;
+            if ((e = dalloc(&h->d_slabrows, mb * L + 64 * (size_t)sosrt_handle::kMaxMixGroups * sosrt_handle::kMaxGroups))) return e;   // + padding
+            if ((e = dalloc(&h->d_slabtilegroup, mb * L / 32 + 2 * sosrt_handle::kMaxMixGroups * sosrt_handle::kMaxGroups + 2))) return e;
             if ((e = dalloc(&h->d_mainrows, mb * L))) return e;
             if ((e = dalloc(&h->d_tau, mb * L))) return e;
             if ((e = dalloc(&h->d_P0a, mb * g.D))) return e;
@@ -804,7 +811,7 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
                             for (int z = 0; z < nz[b]; ++z)
                                 if (gid[b * kMaxZones + z] == k)
                                     for (int t = zr0[b * kMaxZones + z]; t <= zone_end(b, z); ++t) grouped.push_back(b * L + t);
-                        while (grouped.size() % 32) grouped.push_back(-1);
+                        while (grouped.size() % 64) grouped.push_back(-1);   // whole 64-row tiles (two 32-row tiles of the same pair)
                         while (tilegroup.size() < grouped.size() / 32) tilegroup.push_back(k);
                     }
                     h->slab_off[cg + 1] = (int)grouped.size();
@@ -1126,7 +1133,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             // their 32-row tiles put a few columns on more CUs than the dense tiling's 64-row tiles; same bits either way)
             const int tail_cols = (h->contraction != SOSRT_CONTRACT_F32 && h->simple_zones && q.known <= h->gemm_tail_cols &&
                                    (q.known < q.nb || q.nb <= h->gemm_small_cols)) ? q.known : 0;
-            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k);
+            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
                 prof_begin(h, SOSRT_K_SMALLMU, k);

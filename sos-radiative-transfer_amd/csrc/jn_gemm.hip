@@ -76,13 +76,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     const int arow = tid >> 2, akq = (tid & 3) * (GEMM_KC / 4);
     int grow = -1;
     if (arow < BM) grow = row_of(bm0 + arow);
-    if (check_active && g.active) {
+    if (check_active && g.active && g.check_tiles) {
         if (tid == 0) *s_any = 0;
         __syncthreads();
         if ((tid & 3) == 0 && grow >= 0 && g.active[grow / g.L]) *s_any = 1;
         __syncthreads();
         if (!*s_any) return;
     }
+    // the tile's row ids for the epilogue (the lists are read once, here)
+    __shared__ int s_rowid[16 * (GEMM_RT > 2 ? GEMM_RT : 2)];
+    if ((tid & 3) == 0 && arow < BM) s_rowid[arow] = grow;
     const double coef_a = grow >= 0 ? (wmix ? 1.0 : g.ca[grow]) : 0.0;
     const double coef_r = (slab && grow >= 0) ? g.cr[grow] : 0.0;
     const double* __restrict__ Arow = g.A + (size_t)(grow >= 0 ? grow : 0) * D;
@@ -258,7 +261,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     for (int i = 0; i < RT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int gr = row_of(bm0 + i * 16 + 4 * r + fk);
+            const int gr = s_rowid[i * 16 + 4 * r + fk];       // (written before the first barrier of the k loop)
             if (SYM) {
                 const int m = (bn0 >> 1) + wave * 16 + fr;
                 if (gr >= 0 && m < Nn) {

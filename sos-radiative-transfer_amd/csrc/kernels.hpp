@@ -187,6 +187,7 @@ struct GemmArgs {
     // flip-symmetric contraction (jn_gemm.hip, SYM): Wa / Wr / Wmix then hold the folded matrices [k < Ks][S | A]
     int sym = 0;
     int Ks = 0;                      // N rounded up to the k-chunk
+    int check_tiles = 1;             // dense kernel: skip the tiles whose columns have all converged (two barriers and a dependent load per tile)
 };
 
 __device__ inline void publish_live(const GemmArgs& g) {
