@@ -919,56 +919,12 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     if (s_flag[0]) {
         // The first row of a zone has no stop among the lanes of the first lane group, and its blended value is the state of
         // the zone above (spec:403-406 has no bound): redo that
-        // sweep here, row by row, the row exchanged through LDS so that every direction can be a candidate (as the ring
-        // kernel does; rare, written for size).  The rows stored above are read back past the L1 to correct the running
-        // total: I += new - old.
-        double* s_row = s_carry;                                        // [N] (free by now)
-        int& s_kf = *reinterpret_cast<int*>(s_red);
-        const int j = act ? tid : 0;
-        const bool tr = act && tid > 0;
-        const double mu = tr ? g.mu[N + j] : 1.0;
-        const double prmu = tr ? 1.0 / mu : 0.0;
-        const int vo = (N + j) * 8;
+        // sweep here, row by row (redo_upward_sweep).
         // (one workgroup per column: thread tid < N holds direction tid; split: from the surface row, specular or none)
-        double U = SPLIT ? ((act && surface == SOSRT_SURFACE_SPECULAR) ? rho * s_sfc[N - 1 - tid] : 0.0) : Bv;
-        double Jnext = 0;
-        bool missing = false;
+        const double U0 = SPLIT ? ((act && surface == SOSRT_SURFACE_SPECULAR) ? rho * s_sfc[N - 1 - tid] : 0.0) : Bv;
         __syncthreads();
-        for (int t = L - 1; t >= 0; --t) {
-            double Un = 0, Jt = 0;
-            if (act) {
-                Jt = bload(rJ, vo, t * RB);
-                const double Et = bload(rE, vo, t * RB);
-                const double src = rec_src(rec_hr(s_hd[t + 1], prmu), Jnext, Et, Jt);
-                Un = rec_step(U, Et, (t == zend0 || t == zend1) ? 0.0 : src);      // first row of a zone: attenuate only (H4)
-                s_row[j] = tid == 0 ? Jt : Un;                                      // spec:401
-            }
-            if (tid == 0) s_kf = 1 << 30;
-            __syncthreads();
-            if (act && j >= 1 && j <= N - 3 && !(fabs((s_row[j] - s_row[j + 1]) - (s_row[j + 1] - s_row[j + 2])) > 0.0001))
-                atomicMin(&s_kf, j);
-            __syncthreads();
-            const int ks = s_kf;
-            missing |= ks == (1 << 30);
-            const int kf = ks == (1 << 30) ? 1 : ks + 1;
-            double x = act ? s_row[j] : 0.0;
-            if (tr && tid < kf) x = blend_val(blend_weight(mu, 1.0 / g.mu[N + kf]), s_row[0], s_row[kf]);
-            const bool zone_start = t == zbeg1 || t == zbeg2;           // blended row feeds the zone above (H5)
-            U = (zone_start && tr) ? x : Un;
-            Jnext = Jt;
-            if (act) {
-                const double x_old = bload_glc(rIn, vo, t * RB);
-                bstore(rIn, vo, t * RB, x);
-                double It = 0;
-                if (ACC) {
-                    It = bload_glc(rI, vo, t * RB) + (x - x_old);
-                    bstore(rI, vo, t * RB, It);
-                }
-                if (SAVED) bstore(rS, vo, t * RB, x);
-                if (t == 0) { rup_v = x; rup_i = It; }
-            }
-            __syncthreads();
-        }
+        const bool missing = redo_upward_sweep<ACC, SAVED>(L, N, RB, zend0, zend1, zbeg1, zbeg2, s_hd, g.mu, rJ, rE, rIn, rI, rS, U0,
+                                                            s_stage, rup_v, rup_i);
         if (missing) {                                                  // the reference raises IndexError (spec:404)
             if (tid == 0) {
                 a.cv.status[b] = SOSRT_COL_INDEXERROR;

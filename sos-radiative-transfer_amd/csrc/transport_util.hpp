@@ -189,6 +189,80 @@ __device__ bool finish_flagged_rows(const int* s_nf, int L, int N, int RB, const
     return missing;
 }
 
+// The whole upward sweep again, row by row, every direction a candidate of the search: for a column in which the FIRST ROW OF A
+// ZONE has no stop among the lanes of the first wave -- its blended value is the state of the zone above (spec:411,417 after
+// :391-409), so everything above it changes.  Thread tid < N is upward direction N + tid and carries the recurrence
+// from U0 (the reflected surface row); a row goes through LDS for the search and the blend; what the sweep had stored is read
+// back past the L1 to correct the running total, I += new - old.  The rows' loads do not depend on the recurrence: they are
+// issued a chunk of kRedoRows rows ahead, so a row costs two barriers instead of two memory round trips (round 2: 3 us per row,
+// 650 us for a 200-row column that the rest of its launch then waited for).
+// s_work: kRedoRows-independent, 2 N + 4 doubles.  Returns true if some row has no stop at all (IndexError, spec:404).
+constexpr int kRedoRows = 8;
+template <bool ACC, bool SAVED>
+__device__ bool redo_upward_sweep(int L, int N, int RB, int zend0, int zend1, int zbeg1, int zbeg2, const double* s_hd,
+                                  const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rJ, __amdgpu_buffer_rsrc_t rE,
+                                  __amdgpu_buffer_rsrc_t rIn, __amdgpu_buffer_rsrc_t rI, __amdgpu_buffer_rsrc_t rS, double U0,
+                                  double* s_work, double& rup_v, double& rup_i) {
+    const int tid = threadIdx.x;
+    double* s_row = s_work;                                             // [2][N + 2] alternating rows
+    int* s_kf = reinterpret_cast<int*>(s_work + 2 * (N + 2));          // [2]
+    const bool act = tid < N, tr = act && tid > 0;
+    const int j = act ? tid : 0;
+    const double mu = tr ? gmu[N + j] : 1.0;
+    const double prmu = tr ? 1.0 / mu : 0.0;
+    const int vo = (N + j) * 8;
+    double U = U0, Jnext = 0;
+    bool missing = false;
+    if (tid < 2) s_kf[tid] = 1 << 30;
+    __syncthreads();
+    int par = 0;
+    for (int t0 = L - 1; t0 >= 0; t0 -= kRedoRows) {
+        double Jc[kRedoRows], Ec[kRedoRows], xo[kRedoRows], Io[kRedoRows];
+#pragma unroll
+        for (int u = 0; u < kRedoRows; ++u) {
+            const int t = max(t0 - u, 0);
+            Jc[u] = bload(rJ, vo, t * RB);
+            Ec[u] = bload(rE, vo, t * RB);
+            xo[u] = bload_glc(rIn, vo, t * RB);
+            Io[u] = ACC ? bload_glc(rI, vo, t * RB) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kRedoRows; ++u) {
+            const int t = t0 - u;
+            if (t < 0) break;                                           // (uniform)
+            double* row = s_row + par * (N + 2);
+            const double src = rec_src(rec_hr(s_hd[t + 1], prmu), Jnext, Ec[u], Jc[u]);
+            const double Un = rec_step(U, Ec[u], (t == zend0 || t == zend1) ? 0.0 : src);   // first row of a zone: attenuate only (H4)
+            if (act) row[j] = tid == 0 ? Jc[u] : Un;                    // spec:401
+            __syncthreads();
+            if (act && j >= 1 && j <= N - 3 && !(fabs((row[j] - row[j + 1]) - (row[j + 1] - row[j + 2])) > 0.0001)) atomicMin(&s_kf[par], j);
+            if (tid == 0) s_kf[par ^ 1] = 1 << 30;                      // (the other row's slot: read two barriers ago)
+            __syncthreads();
+            const int ks = s_kf[par];
+            missing |= ks == (1 << 30);
+            const int kf = ks == (1 << 30) ? 1 : ks + 1;
+            double x = act ? row[j] : 0.0;
+            if (tr && tid < kf) x = blend_val(blend_weight(mu, 1.0 / gmu[N + kf]), row[0], row[kf]);
+            const bool zone_start = t == zbeg1 || t == zbeg2;           // blended row feeds the zone above (H5)
+            U = (zone_start && tr) ? x : Un;
+            Jnext = Jc[u];
+            if (act) {
+                bstore(rIn, vo, t * RB, x);
+                double It = 0;
+                if (ACC) {
+                    It = Io[u] + (x - xo[u]);
+                    bstore(rI, vo, t * RB, It);
+                }
+                if (SAVED) bstore(rS, vo, t * RB, x);
+                if (t == 0) { rup_v = x; rup_i = It; }
+            }
+            par ^= 1;
+        }
+    }
+    __syncthreads();
+    return missing;
+}
+
 // Python's max() over a row (see block_pymax in kernels.hip); first_tid holds element 0.
 __device__ double block_pymax_(double x, bool valid, double* s_red, int first_tid) {
     const int tid = threadIdx.x, nw = blockDim.x >> 6;
