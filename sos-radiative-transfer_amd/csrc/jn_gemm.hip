@@ -388,6 +388,15 @@ __global__ __launch_bounds__(256, SYM ? kTailWpsSym : 2) void k_jn_gemm_tail(Gem
     __shared__ double sB[GEMM_KC * B_LD];
     gemm_live_columns<TAIL_RT, SYM ? kTailDeepSym : true, SYM>(g, sA, sB);
 }
+// the last few columns (at most kTailDeepCols live): a workgroup is alone on its CU and every k-chunk is a trip to L2 or HBM that
+// nothing else hides, so both operands are staged two chunks ahead (the register budget no longer matters: one workgroup per CU)
+constexpr int kTailDeepCols = 32;
+__global__ __launch_bounds__(256, 2) void k_jn_gemm_tail_deep(GemmArgs g) {
+    publish_live(g);
+    __shared__ double sA[2 * 16 * TAIL_RT * A_LD];
+    __shared__ double sB[GEMM_KC * B_LD];
+    gemm_live_columns<TAIL_RT, true, true>(g, sA, sB);
+}
 
 }  // namespace
 
@@ -399,7 +408,8 @@ void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_til
     const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
     dim3 grid((unsigned)((cols * (ts + tm) + 7) / 8 * 8 * nct));
     if (small_tiles) {
-        if (a.sym) hipLaunchKernelGGL(k_jn_gemm_tail<true>, grid, dim3(256), 0, s, a);
+        if (a.sym && cols <= kTailDeepCols) hipLaunchKernelGGL(k_jn_gemm_tail_deep, grid, dim3(256), 0, s, a);
+        else if (a.sym) hipLaunchKernelGGL(k_jn_gemm_tail<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_jn_gemm_tail<false>, grid, dim3(256), 0, s, a);
     } else {
         if (a.sym) hipLaunchKernelGGL(k_jn_gemm_cols<true>, grid, dim3(256), (size_t)a.pad_lds, s, a);

@@ -10,6 +10,8 @@
 //
 // Layout: every radiance field is [column][layer t][direction m], m fastest, so that one
 // wavefront reads 64 consecutive directions of one layer (512 B, coalesced).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 #include "../../include/sosrt.h"

@@ -253,6 +253,9 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     // Loader `grp` carries the chunks g = grp, grp + SW, ... of both sweeps.  Chunk g goes into stage g mod NST once every
     // lane group has taken chunk g - NST out of it: with NST > SW a residue's next chunk is requested before its current
     // one is even started.
+    // (One chunk in flight per loader.  Up to three -- a counted vmcnt for the oldest, every landed chunk flagged before the loader
+    // blocks on a stage -- was measured again in round 3 on the split form, alternating runs on one box: 32.3 / 32.2 / 33.0 us per
+    // lone-column launch with 1 / 2 / 3 in flight.  The loaders do not set the pace.)
     auto load_chunks = [&](int g0, int g1, bool first_issued) __attribute__((always_inline)) {
         for (int gq = g0; gq < g1; gq += NLOAD) {
             if (gq >= NST)
