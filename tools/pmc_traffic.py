@@ -44,7 +44,7 @@ for f in sorted(set(fetch) | set(write)):
     fb = 2.0 * 1024 * fetch.get(f, 0.0) / max(n, 1)
     wb = 1024 * write.get(f, 0.0) / max(n, 1)
     out[f] = {"launches_per_solve": n / solves, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
-# the transport of a solve: the ring kernel for the first orders, the chunk-parallel kernel from order SOSRT_SCAN_FROM on
+# the transport of a solve: the ring kernel while many columns are live, the chunk-parallel kernel below SOSRT_SCAN_COLS
 tr = [out[k] for k in ("k_transport_ring", "k_transport_scan") if k in out]
 if tr:
     n = sum(x["launches_per_solve"] for x in tr)
@@ -52,6 +52,7 @@ if tr:
     for key in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch"):
         out["k_transport"][key] = sum(x[key] * x["launches_per_solve"] for x in tr) / n
 out["kernel_sources_sha"] = sha()
+out["aerosol"] = os.environ.get("AEROSOL", "eva")
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/run_once.py 512 %d "
                 "(solves of the bench sweep); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streams; counter "
                 "unit KB = 1024 B; averages over all launches, k_jn_gemm = the three tilings of the contraction; bench.py uses this file "

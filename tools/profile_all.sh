@@ -18,9 +18,9 @@ echo "trace done"
 find $O -name "*.csv" | head -20
 # 4. reductions (copied into profiles/ by hand afterwards)
 python3 tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) 1 > $O/pmc_traffic.json
-python3 tools/order_table.py $(find $O/trace -name "*kernel_trace.csv" | head -1) 1 > $O/order_table_ring.txt
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 grep '^{' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
+python3 tools/order_table.py $(find $O/trace -name "*kernel_trace.csv" | head -1) 1 > $O/order_table.txt
 # 5. the plain bench line (default flags)
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/trace
