@@ -128,7 +128,11 @@ struct sosrt_handle {
     double *d_Jn = nullptr, *d_InA = nullptr, *d_InB = nullptr, *d_I = nullptr, *d_E = nullptr;
     int use_etab = 1;
     // convergence
-    int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_nactive = nullptr, *d_redo = nullptr, *d_erep = nullptr;
+    int *d_active = nullptr, *d_norders = nullptr, *d_status = nullptr, *d_redo = nullptr, *d_erep = nullptr;
+    // live columns per group + "some column needs k_smallmu": two sets used by alternate solves, the first kernel of a solve
+    // zeroes the other set (no memset launch at the head of a solve); d_nactive points at the set of the current solve
+    int *d_nactive_sets = nullptr, *d_nactive = nullptr;
+    int nactive_set = 0;
     unsigned long long* d_tauhash = nullptr;
     // 0: general kernel, 1: wave-independent fast kernel (+ repair), 2: LDS-ring kernel, 3 (default): the ring kernel for
     // launches with many live columns (HBM-bound) and the chunk-parallel kernel (transport_scan.hip) for launches with at
@@ -492,7 +496,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_active, mb))) return e;
             if ((e = dalloc(&h->d_norders, mb))) return e;
             if ((e = dalloc(&h->d_status, mb))) return e;
-            if ((e = dalloc(&h->d_nactive, sosrt_handle::kMaxGroups + 1))) return e;   // live columns per group; any column needs k_smallmu
+            if ((e = dalloc(&h->d_nactive_sets, 2 * (sosrt_handle::kMaxGroups + 1)))) return e;   // live columns per group; any column needs k_smallmu
+            HIPCHK(hipMemset(h->d_nactive_sets, 0, 2 * (sosrt_handle::kMaxGroups + 1) * sizeof(int)));
+            h->d_nactive = h->d_nactive_sets;
             if ((e = dalloc(&h->d_redo, mb))) return e;
             if ((e = dalloc(&h->d_erep, mb))) return e;
             if ((e = dalloc(&h->d_mixgroup, mb))) return e;
@@ -533,7 +539,7 @@ int sosrt_destroy(sosrt_t* h) {
         void* ptrs[] = {h->d_mu, h->d_Wa, h->d_Wr, h->d_wfdn, h->d_wfup, h->d_fix, h->d_small, h->d_idx_up,
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
-                        h->d_nactive, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
+                        h->d_nactive_sets, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
                         h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_scan_scratch, h->d_scan_sync, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr};
         for (void* p : ptrs)
             if (p) hipFree(p);
@@ -1017,9 +1023,17 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
 
     prof_break(h);
     // per-sweep setup on the caller's stream: zone tables, shared attenuation tables, combined slab matrices
-    HIPCHK(hipMemsetAsync(h->d_nactive, 0, (sosrt_handle::kMaxGroups + 1) * sizeof(int), s));
+    // this solve's counters were zeroed by the previous solve's first kernel (or at sosrt_create); its own first kernel zeroes
+    // the other set, clears the redo flags and hashes the optical-depth profiles -- one launch instead of four
+    h->nactive_set ^= 1;
+    h->d_nactive = h->d_nactive_sets + h->nactive_set * (sosrt_handle::kMaxGroups + 1);
+    SolveSetup su;
+    su.zero_next = h->d_nactive_sets + (h->nactive_set ^ 1) * (sosrt_handle::kMaxGroups + 1);
+    su.n_zero = sosrt_handle::kMaxGroups + 1;
+    su.redo = h->d_redo;
+    su.hash = h->d_tauhash;
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr,
-                   h->d_nactive + sosrt_handle::kMaxGroups);
+                   h->d_nactive + sosrt_handle::kMaxGroups, su);
     h->need_small = true;
     const int small_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;       // never equals an order tag
     bool small_published = false;
@@ -1037,7 +1051,6 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         launch_attenuation(s, g, B, d_tau, h->d_E, h->d_erep);
         small_published = true;
     }
-    if (fast) HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), s));
     if (int e = ensure_matrices(h, s)) return e;
     if (NG > 1) {                                    // the second column group runs on the internal stream from here on
         HIPCHK(hipEventRecord(h->ev_fork, s));

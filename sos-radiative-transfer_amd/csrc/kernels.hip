@@ -80,9 +80,27 @@ __device__ __forceinline__ int d_fix_bucket(double tau_ref) {
 // ------------------------------------------------------------------------------------------
 __global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, const double* __restrict__ tau,
                           ColDesc* __restrict__ desc, double* __restrict__ rowcoef_a,
-                          double* __restrict__ rowcoef_r, int* __restrict__ need_small) {
+                          double* __restrict__ rowcoef_r, int* __restrict__ need_small, SolveSetup su) {
     const int b = blockIdx.x;
     if (b >= B) return;
+    // The start of a solve (su: all null elsewhere) rides on this launch instead of three more: the counters of the NEXT solve are
+    // zeroed (this solve's were zeroed by the previous one, or at sosrt_create), the column's redo flag is cleared, and the
+    // second wave hashes the column's optical-depth profile (the tau groups of k_tau_rep).
+    if (su.zero_next && b == 0 && threadIdx.x < su.n_zero) su.zero_next[threadIdx.x] = 0;
+    if (su.redo && threadIdx.x == 0) su.redo[b] = 0;
+    if (su.hash && threadIdx.x >= 64) {
+        const int lane = threadIdx.x - 64;
+        const unsigned long long* t = reinterpret_cast<const unsigned long long*>(tau + (size_t)b * g.L);
+        unsigned long long h = 0;
+        for (int i = lane; i < g.L; i += 64) {
+            unsigned long long x = t[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+            x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+            h += x;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+        if (lane == 0) su.hash[b] = h;
+    }
     __shared__ ColDesc d;
     const double* tb = tau + (size_t)b * g.L;
     if (threadIdx.x == 0) {
@@ -151,9 +169,9 @@ __global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, c
 }
 
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
-                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small) {
+                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small, SolveSetup su) {
     hipLaunchKernelGGL(k_prepare, dim3(B), dim3(128), 0, s, g, B, geom, surface, sc, tau, desc, rowcoef_a, rowcoef_r,
-                       need_small);
+                       need_small, su);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1011,8 +1029,8 @@ void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, 
 // per profile keeps the tables in L2 / MALL instead of streaming one per column from HBM in every
 // order.  k_tau_hash: one 64-bit hash per column; k_tau_rep: the first earlier column with the same
 // hash and, checked value by value, the same profile.
-__global__ void k_tau_hash(int L, const double* __restrict__ tau_all, unsigned long long* __restrict__ hash,
-                           const int* __restrict__ need_small, int* __restrict__ host_flag, int tag) {
+__global__ void k_tau_rep(int L, const double* __restrict__ tau_all, const unsigned long long* __restrict__ hash,
+                          int* __restrict__ erep, const int* __restrict__ need_small, int* __restrict__ host_flag, int tag) {
     const int b = blockIdx.x, lane = threadIdx.x;            // one wave per column
     // k_prepare (the previous kernel of the stream) has decided whether any |mu| < 0.01 lane keeps its k_smallmu value: tell
     // the host now, so that the order loop can drop those launches -- and the ring kernel their LDS rows, which lets two
@@ -1021,20 +1039,6 @@ __global__ void k_tau_hash(int L, const double* __restrict__ tau_all, unsigned l
         __hip_atomic_store(host_flag, need_small[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_flag + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const unsigned long long* t = reinterpret_cast<const unsigned long long*>(tau_all + (size_t)b * L);
-    unsigned long long h = 0;
-    for (int i = lane; i < L; i += 64) {
-        unsigned long long x = t[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
-        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
-        h += x;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
-    if (lane == 0) hash[b] = h;
-}
-__global__ void k_tau_rep(int L, const double* __restrict__ tau_all, const unsigned long long* __restrict__ hash,
-                          int* __restrict__ erep) {
-    const int b = blockIdx.x, lane = threadIdx.x;            // one wave per column
     const unsigned long long hb = hash[b];
     const double* tb = tau_all + (size_t)b * L;
     int rep = b;
@@ -1054,8 +1058,8 @@ __global__ void k_tau_rep(int L, const double* __restrict__ tau_all, const unsig
 }
 void launch_tau_groups(hipStream_t s, const Grid& g, int B, const double* tau, unsigned long long* hash, int* erep,
                        const int* need_small, int* host_flag, int tag) {
-    hipLaunchKernelGGL(k_tau_hash, dim3(B), dim3(64), 0, s, g.L, tau, hash, need_small, host_flag, tag);
-    hipLaunchKernelGGL(k_tau_rep, dim3(B), dim3(64), 0, s, g.L, tau, hash, erep);
+    // (the hashes come from k_prepare, the kernel before this one)
+    hipLaunchKernelGGL(k_tau_rep, dim3(B), dim3(64), 0, s, g.L, tau, hash, erep, need_small, host_flag, tag);
 }
 
 template <int MAXT>

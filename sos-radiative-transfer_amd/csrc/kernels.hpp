@@ -140,8 +140,15 @@ void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a);
 extern int g_ring_slots, g_ring_debug;                        // tuning (SOSRT_RING_SLOTS)
 extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
 
+// what the first kernel of a solve does besides the zone tables (all null: nothing)
+struct SolveSetup {
+    int* zero_next = nullptr;            // [n_zero] counters of the next solve
+    int n_zero = 0;
+    int* redo = nullptr;                 // [B] per-column redo flags, cleared
+    unsigned long long* hash = nullptr;  // [B] hash of the column's optical-depth profile
+};
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
-                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small = nullptr);
+                    ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small = nullptr, SolveSetup su = SolveSetup());
 void launch_first_order_readme(hipStream_t s, const Grid& g, const double* w, int B, const double* tau, const double* P0a,
                                const double* P0r, const ColDesc* desc, double* I1_out, double* I_out, double* saved,
                                size_t saved_col_stride, Conv cv, int do_conv);
