@@ -164,6 +164,28 @@ def test_rows_whose_search_leaves_the_first_wave_are_finished_one_by_one(monkeyp
     assert flagged >= 6
 
 
+@pytest.mark.parametrize("N,surface", [(128, "specular"), (128, "lambertian_readme"), (256, "specular"), (256, "lambertian_readme")])
+def test_long_searches_with_saved_orders_every_surface_and_split(N, surface):
+    """The same kind of column (EVA aerosol, mu0 = 0.2, bright ground: rows of the second order whose search passes lane 61)
+    with the per-order history stored (I_saved, spec:304-305,458), over a specular and a Lambertian surface, at N = 128 and
+    N = 256: two or four workgroups per column (specular), one (Lambertian, N = 128) or the ring kernel (Lambertian, N = 256).
+    Every order against the oracle on identical inputs."""
+    L = 200
+    tg, rg = np.geomspace(0.01, 1.0, 8), np.linspace(0.0, 0.8, 8)
+    mu0, taer, rho = 0.2, float(tg[4]), float(rg[7])
+    P_atm, P_aer, p0 = _oracle_inputs("eva", N, [mu0])
+    r = SOS_Aer(surface, mu0=mu0, nb_layers=L, nb_angles=N, grd_alb=rho, tauStar_atm=0.124, tauStar_aer=taer, alb_aer=0.97,
+                P_atm=P_atm, P0_atm=p0[mu0][0], P_aer=P_aer, P0_aer=p0[mu0][1], max_orders=200)
+    col = O.make_column(mu0, 120, 25, 17, L, 0.124, taer, rho, 1.0, 0.97, N, p0[mu0][0], P_atm, p0[mu0][1], P_aer, surface=surface)
+    ref = O.solve_column(col, literal=False)
+    assert r.n == ref.n and r.I_saved.shape[0] == ref.n
+    assert_close(r.I, ref.I, RTOL, "I")
+    for k in range(ref.n):
+        assert_close(r.I_saved[k], ref.I_saved[k], RTOL, "order %d" % (k + 1))
+    reach = np.argmax(np.abs(np.diff(ref.I_saved[1][:, N:], 2, axis=1)) > 1e-12, axis=1) + 1
+    print("\n[N=%d %s] orders %d, longest search of the second order: lane %d" % (N, surface, ref.n, reach.max()))
+
+
 def test_symmetric_and_full_contraction_agree_on_a_forward_peaked_matrix():
     """What the flip-symmetric form drops is the antisymmetric part of the folded matrices (sosrt.h, sosrt_set_contraction).
     The EVA matrix is the most forward-peaked input of the suite (p(1)/p(-1) = 117, max P = 59): the two forms of the
