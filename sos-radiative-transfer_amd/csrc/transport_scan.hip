@@ -111,12 +111,23 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 #define SCAN_T1() t_pre += clock64() - t_c
 #define SCAN_T2() t_c = clock64()
 #define SCAN_T3() t_post += clock64() - t_c
+#define SCAN_CB(gq_)
+#elif defined(SOSRT_SCAN_CHAIN)   // diagnostic builds: per-chunk timeline [b][4096]: ((part * 128 + chunk) * 5 + k), tools/stamps_chain.py
+    auto stamp = [](int) {};
+    int cgq = 0;
+#define SCAN_C(k_) do { if (a.stamps && lane == 0) a.stamps[(size_t)b * 4096 + (part * 128 + cgq) * 5 + (k_)] = clock64(); } while (0)
+#define SCAN_CB(gq_) do { cgq = (gq_); SCAN_C(0); } while (0)
+#define SCAN_T0() SCAN_C(1)
+#define SCAN_T1() SCAN_C(2)
+#define SCAN_T2() SCAN_C(3)
+#define SCAN_T3() SCAN_C(4)
 #else
     auto stamp = [](int) {};
 #define SCAN_T0()
 #define SCAN_T1()
 #define SCAN_T2()
 #define SCAN_T3()
+#define SCAN_CB(gq_)
 #endif
     stamp(0);
     extern __shared__ double sm[];
@@ -330,6 +341,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             constexpr int MODE = decltype(mode_t)::value;
             const int t0 = q * TC;
             double Jc[TC], Ec[TC], Ic[TC], Jx_;
+            SCAN_CB(q);
             take(q, vo, t0 * RB, RB, Jc, Ec, Ic, Jx_);
             SCAN_T0();
             const double Jprev = q > 0 ? Jx_ : 0.0;
@@ -654,6 +666,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             constexpr int PM = FAST ? MODE - 2 : MODE;          // treatment of the rows: 0 none, 1 transposed blend
             const int t0 = L - 1 - j * TC;
             double Jc[TC], Ec[TC], Ic[TC], Jx_;
+            SCAN_CB(NCH + j);
             take(NCH + j, vo, t0 * RB, -RB, Jc, Ec, Ic, Jx_);
             SCAN_T0();
             const double Jnext = j > 0 ? Jx_ : 0.0;
