@@ -141,9 +141,7 @@ struct sosrt_handle {
     int transport_mode = 3;
     int scan_cols = 200;                 // SOSRT_SCAN_COLS
     bool ring_ok = false, scan_ok = false, scan_split_ok = false;
-    int scan_pw = 0;                     // SOSRT_SCAN_PW: 64 / 32 force the part width of the split form (0: 32 from order scan_pw32_from on)
-    int scan_pw32_from = 6;              // SOSRT_SCAN_PW32_FROM
-    int scan_split = 1;                  // SOSRT_SCAN_SPLIT: several workgroups per column while they fit the device at once
+    int scan_split = 1;                  // SOSRT_SCAN_SPLIT: two workgroups per column when at most half as many columns are live as the device has CUs
     int cu_count = 0;
     double* d_scan_scratch = nullptr;    // [max_batch][transport_scan_scratch_doubles()] exchange rows of the split form
     int* d_scan_sync = nullptr;          // [max_batch][2] {arrivals, flags}, zero between launches
@@ -428,8 +426,6 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
         h->transport_mode = strcmp(ev, "general") == 0 ? 0 : (strcmp(ev, "ring") == 0 ? 2 : (strcmp(ev, "scan") == 0 ? 4 : (strcmp(ev, "auto") == 0 ? 3 : 1)));
     if (const char* ev = getenv("SOSRT_SCAN_COLS")) h->scan_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_SCAN_SPLIT")) h->scan_split = atoi(ev);
-    if (const char* ev = getenv("SOSRT_SCAN_PW")) h->scan_pw = atoi(ev);
-    if (const char* ev = getenv("SOSRT_SCAN_PW32_FROM")) h->scan_pw32_from = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
@@ -1173,13 +1169,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 const int fast_mode = (ring_mode == 3 && want_scan && (h->scan_ok || can_split)) ? 4 : ring_mode;
                 Grid gt = g;
                 if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
-                // ... and on twice as many CUs, in parts of 32 directions, while those fit too: a lone column's sweep is paced by the
-                // memory path of its CUs.  From the sixth order on (SOSRT_SCAN_PW32_FROM): a 32-direction part sees 29 candidates
-                // of the upward mu -> 0+ search, the early orders' searches run longer and their rows would all be finished one by
-                // one after the sweep (correct, but slower than the 64-direction parts)
-                const bool can_split32 = can_split && h->scan_pw != 64 && transport_scan_parts(g, 32) * cols_now <= h->cu_count &&
-                                         (h->scan_pw == 32 || n >= h->scan_pw32_from);
-                const int split = (fast_mode == 4 && can_split) ? (can_split32 ? 2 : 1) : 0;
+                const int split = (fast_mode == 4 && can_split) ? 1 : 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0, split,
                                  h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(), h->d_scan_sync + 2 * q.b0,

@@ -1113,9 +1113,7 @@ void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, co
     TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab, Etab ? erep : nullptr, g_transport_stamps};
     a.slots = ring_slots;
     a.zone_class = zone_class;
-    if (mode == 4 && scan_split && scan_scratch && scan_sync) {      // scan_split: 1 = parts of 64 directions, 2 = parts of 32
-        a.scan_split = 1; a.scan_pw = scan_split == 2 ? 32 : 64; a.scan_scratch = scan_scratch; a.scan_sync = scan_sync;
-    }
+    if (mode == 4 && scan_split && scan_scratch && scan_sync) { a.scan_split = 1; a.scan_scratch = scan_scratch; a.scan_sync = scan_sync; }
     if ((mode == 3 || mode == 4) && accumulate && live > 0 && live < B && live_list) {       // ring / scan kernel over the live columns only
         a.live = live;
         a.live_list = live_list;

@@ -120,7 +120,6 @@ struct TransportArgs {
     int slots = 0;             // ring depth of this launch (0: the default)
     // chunk-parallel kernel, two workgroups per column (transport_scan.hip): exchange rows and {arrivals, flags} per column
     int scan_split = 0;
-    int scan_pw = 64;                  // directions per part of the split chunk-parallel kernel: 64, or 32 (twice the workgroups)
     double* scan_scratch = nullptr;
     int* scan_sync = nullptr;
     // A batch that mixes columns of up to three zones with columns of more: the ring / chunk-parallel kernel takes the first
@@ -135,7 +134,7 @@ void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int
 // transport_scan.hip: the chunks of a sweep dealt to several waves (chunk-local recurrence + carried values)
 bool transport_scan_ok(const Grid& g);
 bool transport_scan_split_ok(const Grid& g);
-int transport_scan_parts(const Grid& g, int pw = 64);          // workgroups per column of the split form: ceil(N / pw), pw = 64 or 32
+int transport_scan_parts(const Grid& g);                       // workgroups per column of the split form: ceil(N / 64)
 size_t transport_scan_scratch_doubles();                       // per column
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a);
 extern int g_ring_slots, g_ring_debug;                        // tuning (SOSRT_RING_SLOTS)

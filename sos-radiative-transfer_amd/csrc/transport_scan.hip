@@ -65,14 +65,8 @@ constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value a
 template <bool ACC, bool SAVED, bool SPLIT>
 __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fixcap) {
     constexpr int SW = ScanCfg<SPLIT>::SW, NST = ScanCfg<SPLIT>::NST, SROW = ScanCfg<SPLIT>::SROW, STAGE = ScanCfg<SPLIT>::STAGE;
-    // SPLIT: ceil(N / PW) workgroups per column, part p = blockIdx.x mod that.  PW = 64 directions per part (two workgroups at
-    // N = 128, four at N = 256), or 32 (four at N = 128, eight at N = 256): a lone column's sweep is paced by the memory path
-    // of the CU it runs on -- the per-chunk timeline shows a CU taking in a chunk (8.7 KB of Jn and attenuation rows) per
-    // ~450-500 cycles however many are requested at once -- so halving a part's directions halves what each CU has to move.
-    // A 32-direction part uses half the lanes of its waves; its mu -> 0+ search sees 29 candidates instead of 61, and a row
-    // that needs more is flagged and finished after the sweep like any other (api.hip takes this form from the sixth order on).
-    const int PW = SPLIT ? (a.scan_pw == 32 ? 32 : 64) : 64;
-    const int nparts = SPLIT ? (a.g.N + PW - 1) / PW : 1;
+    // SPLIT: ceil(N / 64) workgroups per column (two at N = 128, four at N = 256), part p = blockIdx.x mod that
+    const int nparts = SPLIT ? (a.g.N + 63) >> 6 : 1;
     const int part = SPLIT ? (int)(blockIdx.x % nparts) : 0;
     int b = SPLIT ? (int)(blockIdx.x / nparts) : (int)blockIdx.x;
     if (ACC && a.live > 0) {
@@ -93,18 +87,17 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     const int lg = wid % nwc, grp = loader ? wid - ncw : wid / nwc;   // this wave: 64 directions, chunks grp, grp + SW, ... (loaders: grp, grp + NLOAD, ...)
     // downward direction dir_dn, then upward direction N + dir; split: part p = upward 64p .. 64p+63 and their mirror images,
     // the downward directions N-64(p+1) .. N-64p-1 (the last part of an N that is no multiple of 64: from 0)
-    const int dir = SPLIT ? part * PW + lane : lg * 64 + lane;
-    const int dn0 = SPLIT ? max(N - PW * (part + 1), 0) : 0;   // first downward direction of this part
+    const int dir = SPLIT ? part * 64 + lane : lg * 64 + lane;
+    const int dn0 = SPLIT ? max(N - 64 * (part + 1), 0) : 0;   // first downward direction of this part
     const int dir_dn = SPLIT ? dn0 + lane : dir;
-    const bool valid = dir < N && lane < PW;
-    const bool valid_dn = SPLIT ? (dir_dn < N - PW * part && lane < PW) : valid;
+    const bool valid = dir < N;
+    const bool valid_dn = SPLIT ? dir_dn < N - 64 * part : valid;
     const int dirc = valid ? dir : N - 1;
     const int dirc_dn = valid_dn ? dir_dn : 0;
     const bool w0 = !loader && (SPLIT ? part == 0 : lg == 0);                    // holds the mu -> 0+ lanes
     const bool wl = !loader && (SPLIT ? part == 0 : lg == ((N - 1) >> 6));       // holds the mu -> 0- lanes
-    const int lane_last = SPLIT ? PW - 1 : ((N - 1) & 63);     // lane of downward direction N-1 in the wave that holds it
-    const int dn_base = SPLIT ? N - PW : (((N - 1) >> 6) << 6);  // downward direction of lane 0 of that wave
-    const int SROWr = SPLIT ? PW : SROW;                       // doubles per staged row (the stages keep their stride)
+    const int lane_last = SPLIT ? 63 : ((N - 1) & 63);         // lane of downward direction N-1 in the wave that holds it
+    const int dn_base = SPLIT ? N - 64 : (((N - 1) >> 6) << 6);  // downward direction of lane 0 of that wave
     const int nwaves = blockDim.x >> 6;
     const int NCH = (L + TC - 1) / TC;
 
@@ -237,10 +230,10 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         asm volatile("" ::: "memory");                      // (compiler only: the reads stay between the two flag accesses)
 #pragma unroll
         for (int u = 0; u < TC; ++u) {
-            J[u] = st[(0 * TC + u) * SROWr];
-            E[u] = st[(1 * TC + u) * SROWr];
+            J[u] = st[(0 * TC + u) * SROW];
+            E[u] = st[(1 * TC + u) * SROW];
         }
-        Jx = st[(2 * TC) * SROWr];
+        Jx = st[(2 * TC) * SROW];
         asm volatile("" ::: "memory");
         if (lane == 0) l_taken[stg * nwc + lg] = gq + 1;
         // (requested here, after the stage has been taken: asked for before the wait for the stage -- more lead time on paper --
@@ -256,95 +249,54 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         double* dst = s_stage + (size_t)(gq % NST) * STAGE;
         const int t0 = up ? L - 1 - q * TC : q * TC;
         // byte offset of this workgroup's directions in a row: the half row (1 KiB pieces), or -- split -- its 64 directions (512 B)
-        const int half = SPLIT ? (up ? N * 8 + part * PW * 8 : dn0 * 8) : (up ? N * 8 : 0);
-#ifdef SOSRT_SCAN_ISSUE17          // (A/B builds: one row per instruction, as before round 3)
-        constexpr bool kPairRows = false;
-#else
-        constexpr bool kPairRows = SPLIT;
-#endif
-        if (kPairRows) {
-            // A staged row of the split form is 512 B (256 B with 32-direction parts), a half or a quarter of what one
-            // `buffer_load_dwordx4 ... lds` moves: the wave's lanes take 2 (4) consecutive rows of the stage (the row offset goes
-            // into the per-lane address, the LDS destination is contiguous), 9 (5) instructions per chunk instead of 17.
-            const int lpr = PW >> 1, rpi = 64 / lpr;             // 16-byte lanes per row, rows per instruction
-            const int hl = lane / lpr, vl = (lane % lpr) * 16;
-            for (int u = 0; u < TC; u += rpi) {
+        const int half = SPLIT ? (up ? N * 8 + part * 512 : dn0 * 8) : (up ? N * 8 : 0);
+        if (SPLIT) {
+            // A staged row of the split form is 512 B, half of what one `buffer_load_dwordx4 ... lds` moves: the two halves of
+            // the wave take two consecutive rows of the stage (the row offset goes into the per-lane address, the LDS
+            // destination is contiguous), 9 instructions per chunk instead of 17: a lone column's launch 32.6 -> 30.6 us
+            // (alternating builds on one box, round 3).
+            const int hl = lane >> 5, vl = (lane & 31) * 16;
+#pragma unroll
+            for (int u = 0; u < TC; u += 2) {
                 const int uu = u + hl;
                 const int row = up ? max(t0 - uu, 0) : min(t0 + uu, L - 1);
                 const int vo = vl + row * RB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROWr), 16, vo, half, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROWr), 16, vo, half, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROW), 16, vo, half, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROW), 16, vo, half, 0, 0);
             }
             const int rx = up ? min(t0 + 1, L - 1) : max(t0 - 1, 0);     // the row before the chunk (unused by the first chunk)
-            if (lane < lpr) __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROWr), 16, vl, rx * RB + half, 0, 0);
-        } else if (!SPLIT || lane < 32) {
+            if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROW), 16, vl, rx * RB + half, 0, 0);
+        } else {
             const int vo = lane * 16;
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
                 const int row = up ? max(t0 - u, 0) : min(t0 + u, L - 1);
                 const int so = row * RB + half;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROWr), 16, vo, so, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROWr), 16, vo, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROW), 16, vo, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROW), 16, vo, so, 0, 0);
             }
             const int rx = up ? min(t0 + 1, L - 1) : max(t0 - 1, 0);     // the row before the chunk (unused by the first chunk)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROWr), 16, vo, rx * RB + half, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROW), 16, vo, rx * RB + half, 0, 0);
         }
     };
     // Loader `grp` carries the chunks g = grp, grp + SW, ... of both sweeps.  Chunk g goes into stage g mod NST once every
     // lane group has taken chunk g - NST out of it: with NST > SW a residue's next chunk is requested before its current
     // one is even started.
-    // Split form: a loader keeps up to DEPTH chunks in flight (12 stages for 4 loaders) and waits with a counted vmcnt for
-    // the oldest only (a chunk is IPC vector-memory instructions, whatever the exec mask).  While the stage of its next chunk
-    // has not been taken yet it keeps flagging what lands -- the computing waves take the chunks in order, so a landed but
-    // unflagged chunk ahead of the awaited one would stop them for good -- without draining what is still in flight.
-    // (A first version that drained everything before blocking measured no gain: in the steady state a loader always finds
-    // its next stage still in use, so it always drained.)
-#ifdef SOSRT_SCAN_DEPTH             // (A/B builds)
-    constexpr int DEPTH = SPLIT ? SOSRT_SCAN_DEPTH : 1;
-#else
-    constexpr int DEPTH = SPLIT ? 3 : 1;
-#endif
-    // vector-memory instructions per chunk: 17 (one row each), 9 (two rows each, PW = 64) or 5 (four rows each, PW = 32)
-#ifdef SOSRT_SCAN_ISSUE17
-    const int IPC = 2 * TC + 1;
-#else
-    const int IPC = SPLIT ? (PW == 32 ? TC / 2 + 1 : TC + 1) : 2 * TC + 1;
-#endif
+    // (One chunk in flight per loader.  Up to three -- a counted vmcnt for the oldest, landed chunks flagged while the loader waits
+    // for a stage, nothing drained -- was measured twice in round 3 on the split form, alternating builds on one box: 30.5 vs 30.5 us
+    // per lone-column launch.  The per-chunk timeline (tools/stamps_chain.py) shows why: twelve chunks requested at once arrive
+    // eight by cycle 2 400 and four by 5 000 - 7 000 -- a CU takes in a chunk per ~450-500 cycles however many are in flight.
+    // Halving what a CU has to move -- parts of 32 directions on twice the CUs, half the lanes of every wave -- did not help
+    // either (40.3 vs 40.2 us in a build that made the part width a run-time value, which by itself cost 10 us: these waves
+    // are bound by their instruction streams).)
     auto load_chunks = [&](int g0, int g1, bool first_issued) __attribute__((always_inline)) {
-        int pend = 0, oldest = g0;
-        auto land_oldest = [&]() __attribute__((always_inline)) {      // wait for the oldest chunk in flight, raise its flag
-            // (all but the pend - 1 youngest chunks have landed; the count is an immediate)
-            const int keep = (pend - 1) * IPC;
-            if (keep >= 34) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
-            else if (keep >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            else if (keep >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            else if (keep >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (keep >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else if (keep >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) l_landed[oldest % NST] = oldest + 1;
-            oldest += NLOAD;
-            --pend;
-        };
         for (int gq = g0; gq < g1; gq += NLOAD) {
-            if (gq >= NST) {
-                for (int i = 0; i < nwc; ++i) {
-                    lds_vint* f = l_taken + (gq % NST) * nwc + i;
-                    unsigned it = 0;
-                    while (*f != gq - NST + 1) {
-                        if (pend > 0) land_oldest();
-                        else {
-                            __builtin_amdgcn_s_sleep(1);
-                            if (++it > kSpinLimit) { s_flag[2] = 1; break; }
-                        }
-                    }
-                }
-            }
+            if (gq >= NST)
+                for (int i = 0; i < nwc; ++i) spin(l_taken + (gq % NST) * nwc + i, gq - NST + 1);
             if (!(first_issued && gq == g0)) issue(gq);
-            ++pend;
-            if (pend == DEPTH) land_oldest();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) l_landed[gq % NST] = gq + 1;
         }
-        while (pend > 0) land_oldest();
     };
     // the chunks a loader may carry before the turn-round: those whose stage was last used by a downward chunk
     const int g_seam = min(NCH + NST, 2 * NCH);
@@ -701,7 +653,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         const bool tr = valid && dir > 0;
         const double mu = mu_up;
         const double prmu = tr ? 1.0 / mu : 0.0;
-        const int last_cand = min(N - 3, (SPLIT ? PW : 64) - 3);
+        const int last_cand = min(N - 3, 61);
         bool notfound = false;
         // spec:401-409 for one row held across the first lane group: x is the raw row, returns the blended value
         // (no stop among the candidates of this lane group: the row stays raw and is finished after the sweep,
@@ -714,7 +666,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             const int kf = mk ? __ffsll((long long)mk) : 1;
             if (mk == 0) {
                 notfound = true;
-                if (N - 3 > last_cand && lane == 0 && t >= 0) {
+                if (N - 3 > 61 && lane == 0 && t >= 0) {
                     if (t == zbeg1 || t == zbeg2) s_flag[0] = 1;
                     else { flag_row(s_nf, t); s_flag[3] = 1; }
                 }
@@ -908,7 +860,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             else if (!w0) chunk(std::false_type{}, M0{}, j);
             else chunk(std::false_type{}, M1{}, j);
         }
-        if (w0 && notfound && lane == 0 && N - 3 <= last_cand) s_flag[1] = 1;     // every candidate was in this lane group: IndexError
+        if (w0 && notfound && lane == 0 && N - 3 <= 61) s_flag[1] = 1;     // every candidate was in this lane group: IndexError
     }
     stamp(4);
     __syncthreads();
@@ -1088,13 +1040,13 @@ bool transport_scan_split_ok(const Grid& g) {
     if ((g.L + TC - 1) / TC > 64) return false;
     return scan_lds_bytes<true>(g) <= kScanLdsBytes;
 }
-int transport_scan_parts(const Grid& g, int pw) { return pw == 32 ? (g.N + 31) / 32 : (g.N + 63) / 64; }
+int transport_scan_parts(const Grid& g) { return (g.N + 63) / 64; }
 size_t transport_scan_scratch_doubles() { return kScanScratch; }
 
 // a.scan_split: two workgroups per column (the grid is then twice the columns; specular surface or none; a.scan_scratch /
 // a.scan_sync: kScanScratch doubles and two zeroed ints per column of the batch)
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a) {
-    if (a.scan_split && a.accumulate) launch_scan_t<true>(s, dim3(transport_scan_parts(a.g, a.scan_pw) * grid.x), a);
+    if (a.scan_split && a.accumulate) launch_scan_t<true>(s, dim3(transport_scan_parts(a.g) * grid.x), a);
     else launch_scan_t<false>(s, grid, a);
 }
 

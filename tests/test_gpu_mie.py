@@ -131,10 +131,9 @@ def test_rows_whose_search_leaves_the_first_wave_are_finished_one_by_one(monkeyp
     kw = dict(tauStar_atm=0.124, alb_aer=0.97, nb_layers=L, nb_angles=N, z_up=25, z_down=17, max_orders=200,
               P_atm=P_atm, P_aer=P_aer, P0_atm=P0a, P0_aer=P0r)
     out = {}
-    for tag, env in (("ring", dict(SOSRT_TRANSPORT="ring")), ("scan2", dict(SOSRT_TRANSPORT="scan", SOSRT_SCAN_PW="64")),
-                     ("scan4", dict(SOSRT_TRANSPORT="scan", SOSRT_SCAN_PW="32")),      # four workgroups per column, 29 candidates each row
+    for tag, env in (("ring", dict(SOSRT_TRANSPORT="ring")), ("scan2", dict(SOSRT_TRANSPORT="scan")),
                      ("scan1", dict(SOSRT_TRANSPORT="scan", SOSRT_SCAN_SPLIT="0")), ("general", dict(SOSRT_TRANSPORT="general"))):
-        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_SPLIT", "SOSRT_SCAN_PW"):
+        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                     # (part of the solver cache's key / read when the handle is created)
@@ -147,7 +146,7 @@ def test_rows_whose_search_leaves_the_first_wave_are_finished_one_by_one(monkeyp
         s_.close()
     M._solvers.clear()
     ring = out["ring"]
-    for tag in ("scan1", "scan2", "scan4"):
+    for tag in ("scan1", "scan2"):
         assert np.array_equal(out[tag].n, ring.n) and np.array_equal(out[tag].I, ring.I), tag
     iu, idn = inputs.slab_indices(120, 25, 17, L)
     flagged = 0

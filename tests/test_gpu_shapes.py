@@ -360,7 +360,7 @@ def test_transport_kernel_follows_the_live_count_with_the_same_bits(monkeypatch)
     kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=72, nb_angles=64, max_orders=200)
 
     def fresh(**env):
-        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_COLS", "SOSRT_SCAN_SPLIT", "SOSRT_SCAN_PW"):
+        for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_COLS", "SOSRT_SCAN_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -371,8 +371,7 @@ def test_transport_kernel_follows_the_live_count_with_the_same_bits(monkeypatch)
     fresh(SOSRT_TRANSPORT="ring")
     ring = SOS_Aer_batch(mu0, taer, rho, **kw)
     assert (ring.status == 0).all() and ring.n.max() >= 14 and ring.n.min() < 14
-    for env in ({"SOSRT_TRANSPORT": "scan"}, {"SOSRT_TRANSPORT": "scan", "SOSRT_SCAN_SPLIT": "0"}, {"SOSRT_SCAN_COLS": "12"},
-                {"SOSRT_TRANSPORT": "scan", "SOSRT_SCAN_PW": "32"}, {"SOSRT_TRANSPORT": "scan", "SOSRT_SCAN_PW": "64"}, {}):
+    for env in ({"SOSRT_TRANSPORT": "scan"}, {"SOSRT_TRANSPORT": "scan", "SOSRT_SCAN_SPLIT": "0"}, {"SOSRT_SCAN_COLS": "12"}, {}):
         fresh(**env)
         whole = SOS_Aer_batch(mu0, taer, rho, **kw)
         assert np.array_equal(whole.n, ring.n) and (whole.status == 0).all()
@@ -399,9 +398,8 @@ def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
     rho = rng.uniform(0.0, 0.8, B)
     kw = dict(tauStar_atm=0.124, alb_aer=0.9, nb_layers=L, nb_angles=N, max_orders=120, raise_on_error=False, z_up=80, z_down=40)
     out = {}
-    for mode in ("ring", "scan", "scan32"):               # scan32: parts of 32 directions from the first order on
-        monkeypatch.setenv("SOSRT_TRANSPORT", mode[:4])
-        monkeypatch.setenv("SOSRT_SCAN_PW", "32" if mode == "scan32" else "64")
+    for mode in ("ring", "scan"):
+        monkeypatch.setenv("SOSRT_TRANSPORT", mode)
         for s_ in list(M._solvers.values()):
             s_.close()
         M._solvers.clear()
@@ -409,13 +407,11 @@ def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
     for s_ in list(M._solvers.values()):
         s_.close()
     M._solvers.clear()
-    a = out["ring"]
-    for mode in ("scan", "scan32"):
-        b = out[mode]
-        assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status), mode
-        live = a.status == 0
-        if live.any():
-            assert np.array_equal(b.I[live], a.I[live]), mode
+    a, b = out["ring"], out["scan"]
+    assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
+    live = a.status == 0
+    if live.any():
+        assert np.array_equal(b.I[live], a.I[live])
 
 
 def test_three_zone_columns_keep_their_bits_beside_columns_of_more_zones():
