@@ -32,6 +32,7 @@
 // (-DSOSRT_SCAN_STAMPS, tools/stamps_scan.py): 35 us, of which a computing wave spends a third waiting (stage, carried value)
 // -- the memory path of the one CU is the bound (six waves per lane group instead of four: the same time).  Hence the
 // SPLIT form below, two workgroups per column: 33-35 us.
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/sosrt.h"
@@ -62,11 +63,15 @@ constexpr size_t kScanLdsBytes = 152 * 1024;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value arrives within a few thousand polls)
 
-template <bool ACC, bool SAVED, bool SPLIT>
+// NC: the number of directions per hemisphere as a compile-time constant (0: taken from the grid).  The computing waves of a lone
+// column are bound by their instruction streams (a run-time stride in the stage reads alone cost 10 us per launch when it was
+// tried); with N fixed the row stride, the direction offsets and the part arithmetic become immediates.  The two sizes of the
+// BASELINE configurations are instantiated for the split form, which is the one that transports lone columns.
+template <bool ACC, bool SAVED, bool SPLIT, int NC = 0>
 __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fixcap) {
     constexpr int SW = ScanCfg<SPLIT>::SW, NST = ScanCfg<SPLIT>::NST, SROW = ScanCfg<SPLIT>::SROW, STAGE = ScanCfg<SPLIT>::STAGE;
     // SPLIT: ceil(N / 64) workgroups per column (two at N = 128, four at N = 256), part p = blockIdx.x mod that
-    const int nparts = SPLIT ? (a.g.N + 63) >> 6 : 1;
+    const int nparts = SPLIT ? ((NC ? NC : a.g.N) + 63) >> 6 : 1;
     const int part = SPLIT ? (int)(blockIdx.x % nparts) : 0;
     int b = SPLIT ? (int)(blockIdx.x / nparts) : (int)blockIdx.x;
     if (ACC && a.live > 0) {
@@ -79,7 +84,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     const Grid& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
-    const int L = g.L, N = g.N, D = g.D;
+    const int L = g.L, N = NC ? NC : g.N, D = 2 * N;
+    if (NC) fixcap = (int)(0.06 * NC) + 1;                     // (scan_fixcap, as an immediate)
     const int nwc = SPLIT ? 1 : (N + 63) >> 6;                 // lane groups of this workgroup
     const int ND = ((N + 63) >> 6) * 64;                       // stride of the per-direction LDS rows
     const int ncw = nwc * SW;                                  // computing waves; the NLOAD loader waves follow
@@ -215,7 +221,10 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     // The rows of chunk g (0 .. NCH-1: downward, NCH ..: upward) out of its stage (the loader has raised the flag), and the
     // stage back to the loaders at once.  The LDS serves the reads before the word that follows them.  The running total
     // does not go through the stage (LDS): the wave asks for its rows itself here and needs them only for its stores.
-    auto take = [&](int gq, int vo_, int so0, int dso, double (&J)[TC], double (&E)[TC], double (&I)[TC], double& Jx) __attribute__((always_inline)) {
+    // (clamp_t: whether rows of the chunk may fall outside the column -- the last chunk of a sweep only; a plain chunk's eight
+    // row offsets are then plain additions: no measurable difference, alternating builds on one box)
+    auto take = [&](auto clamp_t, int gq, int vo_, int so0, int dso, double (&J)[TC], double (&E)[TC], double (&I)[TC], double& Jx) __attribute__((always_inline)) {
+        constexpr bool CLAMP = decltype(clamp_t)::value;
         const int stg = gq % NST;
 #ifdef SOSRT_SCAN_STAMPS
         const unsigned long long tw_ = t_wait;
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         // (requested here, after the stage has been taken: asked for before the wait for the stage -- more lead time on paper --
         // a lone column's launch takes 37 us instead of 32, alternating builds on one box, round 3)
 #pragma unroll
-        for (int u = 0; u < TC; ++u) I[u] = ACC ? bload(rI, vo_, min(max(so0 + u * dso, 0), (L - 1) * RB)) : 0.0;
+        for (int u = 0; u < TC; ++u) I[u] = ACC ? bload(rI, vo_, CLAMP ? min(max(so0 + u * dso, 0), (L - 1) * RB) : so0 + u * dso) : 0.0;
     };
 
     // ------------------------------- loader side -------------------------------
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             const int t0 = q * TC;
             double Jc[TC], Ec[TC], Ic[TC], Jx_;
             SCAN_CB(q);
-            take(q, vo, t0 * RB, RB, Jc, Ec, Ic, Jx_);
+            take(special_t, q, vo, t0 * RB, RB, Jc, Ec, Ic, Jx_);
             SCAN_T0();
             const double Jprev = q > 0 ? Jx_ : 0.0;
             // extrapolation table of the zone (In_limit:113-141 as a linear map): chunk-local copies
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             const int t0 = L - 1 - j * TC;
             double Jc[TC], Ec[TC], Ic[TC], Jx_;
             SCAN_CB(NCH + j);
-            take(NCH + j, vo, t0 * RB, -RB, Jc, Ec, Ic, Jx_);
+            take(special_t, NCH + j, vo, t0 * RB, -RB, Jc, Ec, Ic, Jx_);
             SCAN_T0();
             const double Jnext = j > 0 ? Jx_ : 0.0;
             double cc[TC], v[TC];
@@ -1004,9 +1013,9 @@ void launch_scan_t(hipStream_t s, dim3 grid, const TransportArgs& a) {
     const int nwc = SPLIT ? 1 : (a.g.N + 63) / 64;
     const dim3 block((nwc * C::SW + NLOAD) * 64);
     const size_t shm = scan_lds_bytes<SPLIT>(a.g);
-#define SOSRT_SCAN_LAUNCH(ACC_, SAVED_)                                                                        \
+#define SOSRT_SCAN_LAUNCH_N(ACC_, SAVED_, NC_)                                                                 \
     do {                                                                                                       \
-        auto kern = k_transport_scan<ACC_, SAVED_, SPLIT>;                                                     \
+        auto kern = k_transport_scan<ACC_, SAVED_, SPLIT, NC_>;                                                \
         static bool big_lds = false;                                                                           \
         if (!big_lds) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1015,13 +1024,18 @@ void launch_scan_t(hipStream_t s, dim3 grid, const TransportArgs& a) {
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
     } while (0)
+#define SOSRT_SCAN_LAUNCH(ACC_, SAVED_) SOSRT_SCAN_LAUNCH_N(ACC_, SAVED_, 0)
+    static const bool kFixN = !(getenv("SOSRT_SCAN_NC") && atoi(getenv("SOSRT_SCAN_NC")) == 0);      // (A/B: 0 = the generic instantiation)
     if (a.accumulate) {
         if (a.saved) SOSRT_SCAN_LAUNCH(true, true);
+        else if (SPLIT && kFixN && a.g.N == 128) SOSRT_SCAN_LAUNCH_N(true, false, SPLIT ? 128 : 0);
+        else if (SPLIT && kFixN && a.g.N == 256) SOSRT_SCAN_LAUNCH_N(true, false, SPLIT ? 256 : 0);
         else SOSRT_SCAN_LAUNCH(true, false);
     } else {
         SOSRT_SCAN_LAUNCH(false, false);
     }
 #undef SOSRT_SCAN_LAUNCH
+#undef SOSRT_SCAN_LAUNCH_N
 }
 
 }  // namespace
