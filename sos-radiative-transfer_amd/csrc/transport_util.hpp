@@ -123,8 +123,15 @@ __host__ __device__ inline size_t flagged_rows_work_doubles(int L, int N) { retu
 __device__ __forceinline__ void flag_row(int* s_nf, int t) { atomicOr(&s_nf[t >> 5], 1 << (t & 31)); }
 // All threads of the workgroup call it; thread tid < N is upward direction N + tid.  Returns true if some row has no stop at all
 // (the reference raises IndexError, spec:404).
+// (SOSRT_HELPER_INLINE: the cold helpers below MUST be inlined -- as calls they cost the transport kernels their register
+// allocation: 168 VGPRs and spills reloaded inside the sweeps instead of 131 and none; -DSOSRT_HELPERS_AS_CALLS for A/B builds)
+#ifdef SOSRT_HELPERS_AS_CALLS
+#define SOSRT_HELPER_INLINE __attribute__((noinline))
+#else
+#define SOSRT_HELPER_INLINE __forceinline__
+#endif
 template <bool ACC, bool SAVED>
-__device__ bool finish_flagged_rows(const int* s_nf, int L, int N, int RB, const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rIn,
+__device__ SOSRT_HELPER_INLINE bool finish_flagged_rows(const int* s_nf, int L, int N, int RB, const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rIn,
                                     __amdgpu_buffer_rsrc_t rI, __amdgpu_buffer_rsrc_t rS, double* s_work, double& rup_v, double& rup_i) {
     const int tid = threadIdx.x, NP = N + 2;
     double* s_rows = s_work;
@@ -199,7 +206,7 @@ __device__ bool finish_flagged_rows(const int* s_nf, int L, int N, int RB, const
 // s_work: kRedoRows-independent, 2 N + 4 doubles.  Returns true if some row has no stop at all (IndexError, spec:404).
 constexpr int kRedoRows = 8;
 template <bool ACC, bool SAVED>
-__device__ bool redo_upward_sweep(int L, int N, int RB, int zend0, int zend1, int zbeg1, int zbeg2, const double* s_hd,
+__device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, int zend0, int zend1, int zbeg1, int zbeg2, const double* s_hd,
                                   const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rJ, __amdgpu_buffer_rsrc_t rE,
                                   __amdgpu_buffer_rsrc_t rIn, __amdgpu_buffer_rsrc_t rI, __amdgpu_buffer_rsrc_t rS, double U0,
                                   double* s_work, double& rup_v, double& rup_i) {
@@ -264,7 +271,7 @@ __device__ bool redo_upward_sweep(int L, int N, int RB, int zend0, int zend1, in
 }
 
 // Python's max() over a row (see block_pymax in kernels.hip); first_tid holds element 0.
-__device__ double block_pymax_(double x, bool valid, double* s_red, int first_tid) {
+__device__ __forceinline__ double block_pymax_(double x, bool valid, double* s_red, int first_tid) {
     const int tid = threadIdx.x, nw = blockDim.x >> 6;
     double v = wave_fmax_(valid ? x : __builtin_nan(""));
     __syncthreads();
