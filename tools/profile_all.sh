@@ -5,7 +5,7 @@ O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
 # 1. kernel stats of the bench command (python3 directly after --)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --pipelined 0 > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --pipelined 0 > $O/bench_under_rocprof.log 2>&1
 echo "stats done"
 # 2. PMC passes over one solve each (separate runs, kernel-trace only)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/run_once.py 512 1 > $O/pmc_fetch.log 2>&1
