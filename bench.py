@@ -319,6 +319,8 @@ def main():
     a = ap.parse_args()
     if a.gather is None:
         a.gather = "field" if a.scaling == "strong" else "digest"
+    if a.scaling == "strong" and a.gather == "digest" and a.gpus > 1:
+        raise SystemExit("--scaling strong deals ragged shards: gather the fields (--gather field | abi), not equal-sized digests")
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, before this process touches a GPU
