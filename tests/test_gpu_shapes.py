@@ -626,3 +626,14 @@ def test_zone_table_columns():
     with pytest.raises(ValueError):
         s.set_columns_zones([[0, 20, 10]], [[0, 1, 0]], 0.6, 0.1, 1.0, 0.124 / L, 0.9, 0.01, 0.3)      # not ascending
     s.close()
+
+
+def test_randomised_parity_across_transport_kernels():
+    """tools/fuzz_parity.py: random zone positions, optical depths, albedos, surfaces and N in {64, 100, 128, 192, 256}, phase
+    matrices whose rows oscillate over a random number of upward directions with a random amplitude (long searches in some rows
+    and orders, short ones in others: rows finished one by one, the full redo, the fast path): ring == chunk-parallel bit for
+    bit, every transport kernel against the oracle at 1e-10 with equal order counts or the same IndexError."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    assert fuzz_parity.run(cases=14, seed=20251005, verbose=False) == 0

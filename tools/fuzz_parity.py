@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Randomised parity: columns with random zone positions, optical depths, albedos and surfaces, and phase matrices whose rows
+oscillate over the first J upward directions with a random amplitude -- so that the upward mu -> 0+ search (spec:403-406) runs
+long in some rows and orders and short in others: rows finished one by one, the full row-by-row redo when the first row of a
+zone is hit, the transposed fast path elsewhere -- through the ring kernel, the chunk-parallel kernel (one workgroup and
+ceil(N/64) workgroups per column) and the general kernel: ring == chunk-parallel bit for bit, every kernel against the oracle at
+1e-10 with equal order counts (or IndexError where the oracle raises it).
+    python3 tools/fuzz_parity.py [cases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("sos-radiative-transfer_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np
+import sos_oracle as O
+from sosrt import main as M
+from sosrt.main import SOS_Aer_batch
+from util import rel_err
+
+MODES = (("ring", {"SOSRT_TRANSPORT": "ring"}), ("scan", {"SOSRT_TRANSPORT": "scan"}),
+         ("scan1", {"SOSRT_TRANSPORT": "scan", "SOSRT_SCAN_SPLIT": "0"}), ("general", {"SOSRT_TRANSPORT": "general"}))
+
+
+def run(cases=24, seed=1, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(cases):
+        N = int(rng.choice([64, 100, 128, 128, 192, 256]))
+        L = int(rng.integers(12, 100))
+        z_up = float(rng.uniform(20, 100)); z_down = float(rng.uniform(5, z_up - 5))
+        surface = str(rng.choice(["specular", "specular", "lambertian_readme"]))
+        B = 3
+        mu0 = rng.uniform(0.15, 1.0, B); taer = rng.choice([0.02, 0.1, 0.4, 1.0], B); rho = rng.uniform(0.0, 0.8, B)
+        J = int(rng.choice([0, 20, 50, 66, 70, 90])); amp = float(rng.choice([0.003, 0.02, 0.3]))
+        mu = O.make_mu(N)
+        c = np.ones(2 * N)
+        c[N:] = np.where(np.arange(N) < J, 1 + amp * (-1.0) ** np.arange(N), 1.0)
+        P_atm = O.phase_rayleigh(N, mu, 0.5)[1] * c[:, None]
+        P_aer = O.phase_hg(N, mu, 0.5, float(rng.choice([0.5, 0.7, 0.85])))[1] * c[:, None]
+        P0a = np.stack([O.phase_rayleigh(N, mu, m)[0] for m in mu0]); P0r = np.stack([O.phase_hg(N, mu, m, 0.7)[0] for m in mu0])
+        kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=L, nb_angles=N, z_up=z_up, z_down=z_down, surface=surface,
+                  P_atm=P_atm, P_aer=P_aer, P0_atm=P0a, P0_aer=P0r, max_orders=150, raise_on_error=False)
+        out = {}
+        for tag, env in MODES:
+            if tag == "scan1" and N > 128:
+                continue
+            for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_SPLIT"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            for s_ in list(M._solvers.values()):
+                s_.close()
+            M._solvers.clear()
+            try:
+                out[tag] = SOS_Aer_batch(mu0, taer, rho, **kw)
+            except ValueError as e:           # a slab that does not fit the column (idx_up < 1 ...): same for every mode
+                out[tag] = e
+        if isinstance(out["ring"], Exception):
+            if verbose:
+                print("case %2d L=%3d N=%3d: %s" % (case, L, N, out["ring"]))
+            continue
+        ring = out["ring"]
+        msg = []
+        for tag in out:
+            r = out[tag]
+            if tag in ("scan", "scan1") and not (np.array_equal(r.n, ring.n) and np.array_equal(r.status, ring.status)
+                                                 and np.array_equal(r.I[ring.status == 0], ring.I[ring.status == 0])):
+                msg.append("%s differs from ring in bits" % tag)
+        worst, long_rows = 0.0, 0
+        for b in range(B):
+            col = O.make_column(mu0[b], 120, z_up, z_down, L, 0.124, taer[b], rho[b], 1.0, 0.95, N, P0a[b], P_atm, P0r[b], P_aer, surface=surface)
+            try:
+                ref = O.solve_column(col, literal=False, max_orders=150)
+            except IndexError:
+                for tag in out:
+                    if out[tag].status[b] != 1:
+                        msg.append("%s column %d: oracle raises IndexError, status %d" % (tag, b, out[tag].status[b]))
+                continue
+            for In in ref.I_saved[1:]:
+                reach = np.argmax(np.abs(np.diff(In[:, N:], 2, axis=1)) > 1e-12, axis=1) + 1
+                long_rows += int((reach > 61).sum())
+            for tag in out:
+                r = out[tag]
+                if r.status[b] == 2 and ref.n >= 150:
+                    continue
+                if r.status[b] != 0 or r.n[b] != ref.n:
+                    msg.append("%s column %d: status %d n %d (oracle %d)" % (tag, b, r.status[b], r.n[b], ref.n))
+                    continue
+                e = rel_err(r.I[b], ref.I)
+                worst = max(worst, e)
+                if not e <= 1e-10:
+                    msg.append("%s column %d: rel err %.2e" % (tag, b, e))
+        bad += bool(msg)
+        if verbose or msg:
+            print("case %2d L=%3d N=%3d %-17s J=%2d amp=%.3f  orders %s  rows with a search beyond lane 61: %4d  max rel err %.1e  %s" % (
+                case, L, N, surface, J, amp, ring.n.tolist(), long_rows, worst, "; ".join(msg) if msg else "ok"))
+    for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_SPLIT"):
+        os.environ.pop(k, None)
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    b = run(n, seed)
+    print("cases with a mismatch:", b)
+    sys.exit(1 if b else 0)
