@@ -240,6 +240,7 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         const bool near = fabs(mu + mu0) < 0.0001;          // spec:111
         const bool node = m > N - 2;                         // the mu = 0- node (spec:128-131)
         const double gd = mu0 / (mu0 + mu), gs = mu0 / (mu0 - mu);
+        const double rmu = 1.0 / mu;
         double Ib = 0, vlast = 0;
         for (int z = 0; z < d.nz; ++z) {
             const double qx = (d.wa * pa * d.fa[z] + d.wr[z] * pr * d.fr[z]) * c4pi;       // spec:149
@@ -256,7 +257,9 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             const double ks = exp((t_bd - t_bs) / mu);
             auto row = [&](int t) {
                 const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
-                const double x = exp((tt - t_bd) / mu), xs = x * ks;
+                // ((tt - t_bd) rmu instead of (tt - t_bd) / mu: one rounding of the argument more, |argument| x 1e-16 relative in
+                // the exponential -- inside its own rounding; the division was a fifth of the kernel)
+                const double x = exp((tt - t_bd) * rmu), xs = x * ks;
                 const double before = z ? Ib * x : 0.0;
                 const double direct = near ? q * F0 * e0 * (tt - t_bd) / mu0 : gd * q * F0 * (e0 - e_bd * x);
                 const double surf = gs * qm * R * (eT - e_bs * xs);
@@ -297,6 +300,7 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
         const bool node = j < 1;                             // the mu = 0+ node (spec:221-224)
         const double gd = mu0 / (mu0 + mu), gs = mu0 / (mu0 - mu);
         double Bv = rho * s_sfc[mir];                          // spec:211
+        const double rmu = 1.0 / mu;
         double vlast = 0;
         for (int z = d.nz - 1; z >= 0; --z) {
             const bool bottom = z == d.nz - 1;
@@ -313,7 +317,7 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             const double ku = bottom ? exp(-(t_bu - t_bb) / mu) : 1.0, ksu = exp(-(t_su - t_bb) / mu);
             auto row = [&](int t) {
                 const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
-                const double yb = exp(-(t_bb - tt) / mu);
+                const double yb = exp(-(t_bb - tt) * rmu);
                 const double yu = bottom ? yb * ku : yb;
                 const double ys = yb * ksu;
                 const double before = Bv * yb;

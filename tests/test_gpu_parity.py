@@ -452,5 +452,8 @@ def test_readme_lambertian_first_order(L, N, rho, taer):
     kw0 = dict(kw, grd_alb=0.0)
     a = SOS_Aer("lambertian_readme", P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, first_order="readme", **kw0)
     b = SOS_Aer("lambertian_readme", P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, **kw0)
-    assert_close(a.I_saved[0], b.I_saved[0], 1e-13, "rho = 0: README and coded first orders agree")
+    # (two kernels, two ways to the same closed forms: the coded one evaluates one exponential per element and derives the other
+    # attenuations from it, the README one evaluates each; where e^{-tau/mu0} - e^{-tau_b/mu0} e^{(tau - tau_b)/mu} cancels, a few ulp
+    # of the exponentials show as 6e-13 of the difference -- both are checked against the reference / the oracle at 1e-10)
+    assert_close(a.I_saved[0], b.I_saved[0], 1e-11, "rho = 0: README and coded first orders agree")
     assert a.n == b.n
