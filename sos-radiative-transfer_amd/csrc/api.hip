@@ -95,7 +95,7 @@ struct sosrt_handle {
     int *d_idx_up = nullptr, *d_idx_down = nullptr;
     int *d_nz = nullptr, *d_zr0 = nullptr, *d_zmix = nullptr;     // zone tables [max_batch][kMaxZones]
     double *d_zwr = nullptr, *d_zdtr = nullptr;
-    int max_nz = 1;                      // most zones of any column: beyond three the general transport kernel runs
+    int max_nz = 1;                      // most zones of any column (beyond three: the ring / chunk-parallel kernels' zone-table instantiation; general kernel where the register-streaming one would run)
     bool simple_zones = true;            // every column is (clear, slab, clear): the live-column tilings of the contraction apply
     double* d_scal = nullptr;            // 7 arrays of max_batch
     ColDesc* d_desc = nullptr;
@@ -957,11 +957,14 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     launch_smallmu(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, h->d_desc, nullptr);
     prof_end(h, SOSRT_K_SMALLMU);
     prof_begin(h, SOSRT_K_TRANSPORT);
-    if (h->transport_mode >= 1 && h->fast_ok && h->max_nz <= kRingZones) {
+    const bool ring_like = h->transport_mode >= 2 && h->ring_ok;
+    const int nzcap = h->max_nz > kRingZones ? h->max_nz : kRingZones;
+    if (h->transport_mode >= 1 && h->fast_ok && (h->max_nz <= kRingZones || ring_like)) {
         launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E, nullptr);
         HIPCHK(hipMemsetAsync(h->d_redo, 0, B * sizeof(int), h->stream));
         launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E,
-                         (h->transport_mode == 4 && h->scan_ok) ? 4 : ((h->transport_mode >= 2 && h->ring_ok) ? 3 : 1));
+                         (h->transport_mode == 4 && h->scan_ok && transport_scan_fits(h->g, nzcap, false)) ? 4 : (ring_like ? 3 : 1),
+                         nullptr, 0, nullptr, 0, 0, nullptr, nullptr, nzcap);
         if (h->N - 3 > 61 && !(h->transport_mode >= 2 && h->ring_ok))
             launch_transport(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, nullptr, nullptr, 0, h->d_desc, make_conv(h, 0), 0, 0, h->d_E, 2);
     } else {
@@ -1037,12 +1040,12 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     h->need_small = true;
     const int small_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;       // never equals an order tag
     bool small_published = false;
-    // Columns of more than three zones go through the general kernel.  With the ring / chunk-parallel kernels available the
-    // other columns of such a batch keep theirs (two launches per order, each skipping the other's columns: a column's bits
-    // do not depend on its batch); with the register-streaming kernel the whole batch takes the general one.
+    // The ring / chunk-parallel kernels take columns of any zone count (round 3: the boundaries beyond the reference's two are read
+    // from the column's descriptor, in the chunks that contain one); the register-streaming kernel knows three zones, so a batch
+    // with more goes to the general kernel where that one would run (odd N, N > 256).
     const bool ring_like = h->transport_mode >= 2 && h->ring_ok;
-    const bool mixed = h->transport_mode >= 1 && h->fast_ok && h->max_nz > kRingZones && ring_like;
-    const bool fast = h->transport_mode >= 1 && h->fast_ok && (h->max_nz <= kRingZones || mixed);
+    const bool fast = h->transport_mode >= 1 && h->fast_ok && (h->max_nz <= kRingZones || ring_like);
+    const int nzcap = h->max_nz > kRingZones ? h->max_nz : kRingZones;
     const int ring_mode = (h->transport_mode >= 2 && h->ring_ok) ? 3 : 1;
     if (h->use_etab || fast) {
         // one attenuation table per distinct optical-depth profile
@@ -1166,17 +1169,15 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= h->cu_count &&
                                        (h->surface == SOSRT_SURFACE_SPECULAR || h->surface == SOSRT_SURFACE_NONE);
                 const bool want_scan = h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols);
-                const int fast_mode = (ring_mode == 3 && want_scan && (h->scan_ok || can_split)) ? 4 : ring_mode;
+                const int fast_mode = (ring_mode == 3 && want_scan && ((h->scan_ok && transport_scan_fits(g, nzcap, false)) ||
+                                                                       (can_split && transport_scan_fits(g, nzcap, true)))) ? 4 : ring_mode;
                 Grid gt = g;
                 if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
-                const int split = (fast_mode == 4 && can_split) ? 1 : 0;
+                const int split = (fast_mode == 4 && can_split && transport_scan_fits(g, nzcap, true)) ? 1 : 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                  h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0, split,
                                  h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(), h->d_scan_sync + 2 * q.b0,
-                                 mixed ? 1 : 0);
-                if (mixed)                                 // the columns of more than three zones
-                    launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
-                                     h->d_E, 0, erep_g, 0, nullptr, 0, 0, nullptr, nullptr, 2);
+                                 nzcap);
                 if (h->N - 3 > 61 && fast_mode == 1)     // register-streaming kernel: a search that leaves wave 0 is redone by the
                     launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                      h->d_E, 2, erep_g);         // general kernel (flag cv.redo); the ring kernel redoes it itself

@@ -662,7 +662,6 @@ __global__ __launch_bounds__(MAXT) void k_transport(TransportArgs a) {
     const int b = blockIdx.x;
     if (ACC && !a.cv.active[b]) return;
     if (REPAIR && !a.cv.redo[b]) return;
-    if (a.zone_class == 2 && a.desc[b].nz <= kRingZones) return;      // (the ring / chunk-parallel kernel takes these)
     const Grid& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int L = g.L, N = g.N, D = g.D;
@@ -1111,12 +1110,12 @@ bool transport_fast_ok(const Plan& plan) {
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order,
                       int accumulate, const double* Etab, int mode, const int* erep, int live, const int* live_list,
-                      int ring_slots, int scan_split, double* scan_scratch, int* scan_sync, int zone_class) {
+                      int ring_slots, int scan_split, double* scan_scratch, int* scan_sync, int nzcap) {
     const int nt = round64(g.N);
     const size_t shm = (size_t)(g.L + 2 * TC * (nt + 2) + 2 * nt + nt / 64 + 2) * sizeof(double);
     TransportArgs a{g, tau, Jn, In, I, accumulate ? saved : nullptr, saved_col_stride, desc, cv, order, accumulate, Etab, Etab ? erep : nullptr, g_transport_stamps};
     a.slots = ring_slots;
-    a.zone_class = zone_class;
+    a.nzcap = nzcap > kRingZones ? nzcap : kRingZones;
     if (mode == 4 && scan_split && scan_scratch && scan_sync) { a.scan_split = 1; a.scan_scratch = scan_scratch; a.scan_sync = scan_sync; }
     if ((mode == 3 || mode == 4) && accumulate && live > 0 && live < B && live_list) {       // ring / scan kernel over the live columns only
         a.live = live;

@@ -7,7 +7,7 @@
 namespace sosrt {
 
 constexpr int kMaxZones = 8;       // zones of a column, top to bottom: clear / slab / clear / slab ... (up to four aerosol slabs)
-constexpr int kRingZones = 3;      // the wave-independent transport kernels (fast, ring) handle the reference's three zones
+constexpr int kRingZones = 3;      // zones the register-streaming kernel (fast) handles, and the zones the ring / chunk-parallel kernels keep in scalars
 
 // One independent SOS problem as the kernels see it: a zone table instead of the reference's
 // three copies of every formula (spec:113-449).
@@ -118,14 +118,13 @@ struct TransportArgs {
     int live = 0;
     const int* live_list = nullptr;
     int slots = 0;             // ring depth of this launch (0: the default)
-    // chunk-parallel kernel, two workgroups per column (transport_scan.hip): exchange rows and {arrivals, flags} per column
+    // most zones of any column of the batch (>= kRingZones): sizes the per-zone tables of the ring / chunk-parallel kernels and
+    // selects their instantiation (beyond three zones: the one that tests the other boundaries too)
+    int nzcap = kRingZones;
+    // chunk-parallel kernel, ceil(N / 64) workgroups per column (transport_scan.hip): exchange rows and {arrivals, flags} per column
     int scan_split = 0;
     double* scan_scratch = nullptr;
     int* scan_sync = nullptr;
-    // A batch that mixes columns of up to three zones with columns of more: the ring / chunk-parallel kernel takes the first
-    // kind (zone_class 1), the general kernel the second (zone_class 2), each leaving the other's columns alone, so that a
-    // column keeps the kernel -- and the bits -- it would have alone.  0: every column.
-    int zone_class = 0;
 };
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
@@ -134,6 +133,7 @@ void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int
 // transport_scan.hip: the chunks of a sweep dealt to several waves (chunk-local recurrence + carried values)
 bool transport_scan_ok(const Grid& g);
 bool transport_scan_split_ok(const Grid& g);
+bool transport_scan_fits(const Grid& g, int nzcap, bool split);
 int transport_scan_parts(const Grid& g);                       // workgroups per column of the split form: ceil(N / 64)
 size_t transport_scan_scratch_doubles();                       // per column
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a);
@@ -223,7 +223,7 @@ void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, co
                       double* saved, size_t saved_col_stride, const ColDesc* desc, Conv cv, int order, int accumulate,
                       const double* Etab, int mode, const int* erep = nullptr, int live = 0, const int* live_list = nullptr,
                       int ring_slots = 0, int scan_split = 0, double* scan_scratch = nullptr, int* scan_sync = nullptr,
-                      int zone_class = 0);
+                      int nzcap = kRingZones);
 bool transport_fast_ok(const Plan& plan);
 // erep (nullable): tables are built only for columns with erep[b] == b
 void launch_attenuation(hipStream_t s, const Grid& g, int B, const double* tau, double* Etab, const int* erep);

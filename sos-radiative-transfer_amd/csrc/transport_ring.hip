@@ -45,7 +45,7 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool ACC, bool SAVED, int PIECES>
+template <bool ACC, bool SAVED, int PIECES, bool MZ>
 __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS, int dbg_arg, int fixcap) {
     constexpr int NWL = 2;                                     // loader waves
 #ifdef SOSRT_RING_DEBUG
@@ -61,7 +61,6 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     } else if (ACC && !a.cv.active[b]) {
         return;
     }
-    if (a.zone_class == 1 && a.desc[b].nz > kRingZones) return;       // (the general kernel takes these)
     const Grid& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     // passed the barrier of the last downward chunk by then)
     double* s_sfc = ring + (size_t)NS * SLOT;
     double* s_fixc = s_sfc;
-    double* s_red = s_sfc + max(RS, kRingZones * fixcap * kFixMaxSrc);   // [nw + 1]
+    double* s_red = s_sfc + max(RS, (MZ ? a.nzcap : kRingZones) * fixcap * kFixMaxSrc);      // [nw + 1]  (nzcap: most zones of any column of the batch, >= 3)
     double* s_hd = s_red + (blockDim.x >> 6) + 2;              // [L + 1] half layer thicknesses: hd[t] = (tau[t] - tau[t-1]) / 2
     double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
     double* s_x = s_S + (size_t)g.nsmall * L;                  // [TC][16] the 16 lanes of a mu -> 0 neighbourhood, rows of a chunk
@@ -99,8 +98,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     __shared__ int s_flag[3];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] some row is flagged in s_nf
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
-    const int zend0 = nz > 1 ? dg->r1[0] : -9, zend1 = nz > 2 ? dg->r1[1] : -9;
-    const int zbeg1 = nz > 1 ? dg->r0[1] : -9, zbeg2 = nz > 2 ? dg->r0[2] : -9;
+    const ZoneRows<MZ> zr(dg);                                     // zone boundaries: two in scalars, the others in the descriptor
     const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
     const int surface = dg->surface;
     const double rho = dg->rho;
@@ -120,13 +118,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     // through the general body: one bit per chunk of a sweep.  More than 64 chunks per sweep: every chunk takes the general body.
     unsigned long long sp_dn = NCH > 64 ? ~0ull : 1ull << (NCH - 1), sp_up = sp_dn;
     if (NCH <= 64) {
-        const int zr[4] = {zend0, zend1, zbeg1, zbeg2};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (zr[i] >= 0) {
-                sp_dn |= 1ull << (zr[i] / TC);
-                sp_up |= 1ull << ((L - 1 - zr[i]) / TC);
-            }
+        sp_dn |= zr.boundary_chunks(L, TC, false);
+        sp_up |= zr.boundary_chunks(L, TC, true);
     }
     // The plain chunks between two of those run in a loop of their own.  The general body in the same loop costs the plain
     // chunks a third of their time although they never execute it (register copies where its values join the loop, spilled
@@ -187,7 +180,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     if (loader) {
         for (int q = 0; q < min(R, NQ); ++q) issue(q);
     } else {
-        for (int zz = 0; zz < kRingZones; ++zz) {
+        for (int zz = 0; zz < (MZ ? nz : kRingZones); ++zz) {
             const FixTab& src = g.fix[dg->fixtab[zz]];
             for (int i = tid; i < fixcap * kFixMaxSrc; i += ncomp) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
         }
@@ -246,7 +239,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
         bool fixlane = false;
         auto load_fix = [&](int zz) {
             const double* ftC = s_fixc + zz * fixcap * kFixMaxSrc;
-            nfx = zz == 0 ? nfix0 : (zz == 1 ? nfix1 : nfix2);
+            nfx = zz == 0 ? nfix0 : (zz == 1 ? nfix1 : ((!MZ || zz == 2) ? nfix2 : zr.nfix(zz)));
             const int ns = nfx < 2 ? 2 : (nfx < kFixMaxSrc ? nfx : kFixMaxSrc);     // In_limit:118-141
             fixlane = valid && nfx > 0 && m >= N - nfx;
             const int i = fixlane ? N - 1 - m : 0;
@@ -346,7 +339,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
                     const int t = t0 + u;
-                    if (wl && (t == zbeg1 || t == zbeg2)) load_fix(t == zbeg1 ? 1 : 2);
+                    if (wl) { const int zs = zr.starts(t); if (zs) load_fix(zs); }
                     const double Dn = rec_step(Dv, Ec[u], cc[u]);
                     double x = has_small ? rec_add(Dn, Sc[u]) : Dn;
                     if (wl && nfx > 0) {
@@ -356,7 +349,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                         x = fixlane ? acc : x;
                     }
                     v[u] = x;
-                    const bool zone_end = t == zend0 || t == zend1;     // the next zone starts from the final row (spec:359,378)
+                    const bool zone_end = zr.ends(t);                   // the next zone starts from the final row (spec:359,378)
                     Dv = t < L ? (zone_end ? (stdl ? x : 0.0) : Dn) : Dv;
                     if (valid && t < L) {
                         const int so = t * RB;
@@ -448,7 +441,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
             if (mk == 0) {
                 notfound = true;
                 if (N - 3 > 61 && lane == 0) {
-                    if (t == zbeg1 || t == zbeg2) s_flag[0] = 1;
+                    if (zr.starts(t)) s_flag[0] = 1;
                     else { flag_row(s_nf, t); s_flag[2] = 1; }
                 }
             }
@@ -470,7 +463,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                 const double Jx = u == 0 ? Jnext : Jc[u - 1];
                 const double src = rec_src(rec_hr(hk, prmu), Jx, Ec[u], Jc[u]);
                 // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
-                cc[u] = (SP && (t == zend0 || t == zend1)) ? 0.0 : src;
+                cc[u] = (SP && zr.ends(t)) ? 0.0 : src;
             }
             if (!SP) {
                 {   // chunk-local form, as in the downward sweep
@@ -546,7 +539,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     double x = Un;
                     if (w0 && t >= 0) x = blend(tid == 0 ? Jc[u] : Un, t);
                     v[u] = x;
-                    const bool zone_start = t == zbeg1 || t == zbeg2;   // blended row feeds the zone above
+                    const bool zone_start = zr.starts(t) != 0;          // blended row feeds the zone above
                     U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
                     if (valid && t >= 0) {
                         const int so = t * RB;
@@ -612,7 +605,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     if (s_flag[0]) {
         // The first row of a zone has no stop among the lanes of wave 0, and its blended value is the state of the zone above
         // (spec:403-406 has no bound): redo that sweep here, row by row (redo_upward_sweep; the ring is free by now).
-        const bool missing = redo_upward_sweep<ACC, SAVED>(L, N, RB, zend0, zend1, zbeg1, zbeg2, s_hd, g.mu, rJ, rE, rIn, rI, rS, Bv, ring,
+        const bool missing = redo_upward_sweep<ACC, SAVED, MZ>(L, N, RB, zr, s_hd, g.mu, rJ, rE, rIn, rI, rS, Bv, ring,
                                                             rup_v, rup_i);
         if (missing) {                                                  // the reference raises IndexError (spec:404)
             if (tid == 0) {
@@ -642,8 +635,8 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 // doubles of LDS besides the ring: surface row, reduction slots, half thicknesses, small-mu rows
 // rewritten directions the compact coefficient tables hold: the largest int(c N) of In_limit / I1_In:124-127
 inline int ring_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
-inline size_t ring_extra_doubles(const Grid& g, int nt) {
-    const int rs = g.N <= 128 ? 128 : 256, fc = kRingZones * ring_fixcap(g) * kFixMaxSrc;
+inline size_t ring_extra_doubles(const Grid& g, int nt, int nzcap = kRingZones) {
+    const int rs = g.N <= 128 ? 128 : 256, fc = nzcap * ring_fixcap(g) * kFixMaxSrc;
     return (size_t)(rs > fc ? rs : fc) + nt / 64 + 2 + g.L + 1 + (size_t)g.nsmall * g.L + TC * 16 + 16 + (g.L + 63) / 64;
 }
 
@@ -651,10 +644,10 @@ template <int PIECES>
 void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int NS) {
     const int nt = (int)block.x;
     const int narr = a.accumulate ? 3 : 2;
-    const size_t shm = ((size_t)NS * narr * TC * 128 * PIECES + ring_extra_doubles(a.g, nt)) * sizeof(double);
-#define SOSRT_RING_LAUNCH(ACC_, SAVED_)                                                                        \
+    const size_t shm = ((size_t)NS * narr * TC * 128 * PIECES + ring_extra_doubles(a.g, nt, a.nzcap)) * sizeof(double);
+#define SOSRT_RING_LAUNCH_Z(ACC_, SAVED_, MZ_)                                                                 \
     do {                                                                                                       \
-        auto kern = k_transport_ring<ACC_, SAVED_, PIECES>;                                                    \
+        auto kern = k_transport_ring<ACC_, SAVED_, PIECES, MZ_>;                                               \
         static bool big_lds = false;                                                                           \
         if (!big_lds) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -663,6 +656,12 @@ void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int 
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, g_ring_debug, ring_fixcap(a.g));                           \
     } while (0)
+    // (a batch with a column of more than three zones: the instantiation that reads the other boundaries from the descriptors)
+#define SOSRT_RING_LAUNCH(ACC_, SAVED_)                                                                        \
+    do {                                                                                                       \
+        if (a.nzcap > kRingZones) SOSRT_RING_LAUNCH_Z(ACC_, SAVED_, true);                                     \
+        else SOSRT_RING_LAUNCH_Z(ACC_, SAVED_, false);                                                         \
+    } while (0)
     if (a.accumulate) {
         if (a.saved) SOSRT_RING_LAUNCH(true, true);
         else SOSRT_RING_LAUNCH(true, false);
@@ -670,6 +669,7 @@ void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int 
         SOSRT_RING_LAUNCH(false, false);
     }
 #undef SOSRT_RING_LAUNCH
+#undef SOSRT_RING_LAUNCH_Z
 }
 
 }  // namespace
@@ -694,7 +694,7 @@ void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int
     const int narr = a.accumulate ? 3 : 2;
     const dim3 block((nwc + 2) * 64);
     const size_t slot_bytes = (size_t)narr * TC * 128 * pieces * sizeof(double);
-    const size_t extra = ring_extra_doubles(a.g, (int)block.x) * sizeof(double);
+    const size_t extra = ring_extra_doubles(a.g, (int)block.x, a.nzcap) * sizeof(double);
     int NS = slots < 2 ? 2 : slots;
     while (NS > 2 && NS * slot_bytes + extra > kRingLdsBytes) --NS;
     if (pieces == 1) launch_p<1>(s, grid, block, a, NS);

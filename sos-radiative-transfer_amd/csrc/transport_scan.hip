@@ -67,7 +67,7 @@ constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value a
 // column are bound by their instruction streams (a run-time stride in the stage reads alone cost 10 us per launch when it was
 // tried); with N fixed the row stride, the direction offsets and the part arithmetic become immediates.  The two sizes of the
 // BASELINE configurations are instantiated for the split form, which is the one that transports lone columns.
-template <bool ACC, bool SAVED, bool SPLIT, int NC = 0>
+template <bool ACC, bool SAVED, bool SPLIT, int NC = 0, bool MZ = false>
 __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fixcap) {
     constexpr int SW = ScanCfg<SPLIT>::SW, NST = ScanCfg<SPLIT>::NST, SROW = ScanCfg<SPLIT>::SROW, STAGE = ScanCfg<SPLIT>::STAGE;
     // SPLIT: ceil(N / 64) workgroups per column (two at N = 128, four at N = 256), part p = blockIdx.x mod that
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     } else if (ACC && !a.cv.active[b]) {
         return;
     }
-    if (a.zone_class == 1 && a.desc[b].nz > kRingZones) return;       // (the general kernel takes these)
     const Grid& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
@@ -140,8 +139,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     double* s_stage = sm;                                      // [NST][STAGE] rows of the chunks in flight
     double* s_carry = s_stage + (size_t)NST * STAGE;            // [nwc][CR][64] ring of the values carried into the chunks
     double* s_sfc = s_carry + (size_t)nwc * CR * 64;           // [ND] surface row by downward direction
-    double* s_fixc = s_sfc + ND;                         // [kRingZones][fixcap][kFixMaxSrc] compact extrapolation tables
-    double* s_red = s_fixc + kRingZones * fixcap * kFixMaxSrc; // [nwaves + 2]
+    double* s_fixc = s_sfc + ND;                         // [nzcap][fixcap][kFixMaxSrc] compact extrapolation tables (nzcap: most zones of any column of the batch, >= 3)
+    double* s_red = s_fixc + (MZ ? a.nzcap : kRingZones) * fixcap * kFixMaxSrc;    // [nwaves + 2]
     double* s_hd = s_red + nwaves + 2;                         // [L + 1] half layer thicknesses
     double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
     double* s_prmu = s_S + (size_t)g.nsmall * L;               // [16] 1/mu of the first upward directions
@@ -153,6 +152,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     int* s_landed = s_flagq + nwc * CR;
     int* s_taken = s_landed + NST;
     int* s_nf = s_taken + NST * nwc;                           // [(L + 31) / 32] rows whose mu -> 0+ search left the first lane group (finish_flagged_rows)
+    int* s_nfz = s_nf + (L + 31) / 32;                         // [kMaxZones] rewritten downward directions per zone
     __shared__ int s_flag[4];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] internal, [3] some row is flagged in s_nf
     double* s_x = s_xw + (size_t)(loader ? 0 : wid) * 2 * TC * 16;
     double* s_xI = s_x + TC * 16;
@@ -160,8 +160,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
-    const int zend0 = nz > 1 ? dg->r1[0] : -9, zend1 = nz > 2 ? dg->r1[1] : -9;
-    const int zbeg1 = nz > 1 ? dg->r0[1] : -9, zbeg2 = nz > 2 ? dg->r0[2] : -9;
+    const ZoneRows<MZ> zr(dg);                                     // zone boundaries: two in scalars, the others in the descriptor
     const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
     const int surface = dg->surface;
     const double rho = dg->rho;
@@ -175,15 +174,8 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 
     // chunks with a zone boundary and the last chunk of each sweep: serial form (one bit per chunk of a sweep)
     unsigned long long sp_dn = 1ull << (NCH - 1), sp_up = sp_dn;
-    {
-        const int zr[4] = {zend0, zend1, zbeg1, zbeg2};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (zr[i] >= 0) {
-                sp_dn |= 1ull << (zr[i] / TC);
-                sp_up |= 1ull << ((L - 1 - zr[i]) / TC);
-            }
-    }
+    sp_dn |= zr.boundary_chunks(L, TC, false);
+    sp_up |= zr.boundary_chunks(L, TC, true);
 
 
     // The value carried into chunk q of this lane group, published by the wave of chunk q - 1.  Plain LDS accesses in
@@ -324,11 +316,12 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     // ---- per-column tables ----
     {
         const int nt = blockDim.x;
-        for (int zz = 0; zz < kRingZones; ++zz) {
+        for (int zz = 0; zz < (MZ ? nz : kRingZones); ++zz) {
             const FixTab& src = g.fix[dg->fixtab[zz]];
             for (int i = tid; i < fixcap * kFixMaxSrc; i += nt) s_fixc[zz * fixcap * kFixMaxSrc + i] = src.C[i];
         }
         if (tid < 4) s_flag[tid] = 0;
+        if (tid < kMaxZones) s_nfz[tid] = tid < nz ? dg->nfix[tid] : 0;
         for (int i = tid; i < nwc * CR + NST + NST * nwc + (L + 31) / 32; i += nt) s_flagq[i] = 0;
         const double* __restrict__ tau = a.tau + (size_t)b * L;
         for (int t = tid; t <= L; t += nt) s_hd[t] = (t == 0 || t == L) ? 0.0 : (tau[t] - tau[t - 1]) * 0.5;
@@ -359,11 +352,13 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         const bool has_small = wl && g.nsmall > 0;
         const int sbase = small ? (m - g.small_lanes[0]) * L : 0;   // the small lanes are consecutive directions
         const int lmT = lane_last - pT;                        // lane of direction N-1-pT in the wave that holds it
-        auto zone_of = [&](int t) __attribute__((always_inline)) { return (zbeg2 >= 0 && t >= zbeg2) ? 2 : ((zbeg1 >= 0 && t >= zbeg1) ? 1 : 0); };
+        auto zone_of = [&](int t) __attribute__((always_inline)) { return zr.of(t); };
         // (by shifts: a chain of selects over the three captured counts becomes a table of pointers on the stack, read back
         // with FLAT loads that wait for every global load and store in flight)
         const int nfix_packed = nfix0 | (nfix1 << 10) | (nfix2 << 20);
-        auto nfix_of = [&](int zz) __attribute__((always_inline)) { return (nfix_packed >> (10 * zz)) & 1023; };
+        // (zones beyond the third -- columns of more than one aerosol layer -- from the table in LDS)
+        auto nfix_of = [&](int zz) __attribute__((always_inline)) { if constexpr (MZ) { if (zz > 2) return s_nfz[min(zz, kMaxZones - 1)]; }
+            return (nfix_packed >> (10 * zz)) & 1023; };
         // one chunk: rows t0 .. t0 + TC - 1
         auto chunk = [&](auto special_t, auto mode_t, int q) __attribute__((always_inline)) {
             constexpr bool SP = decltype(special_t)::value;
@@ -489,7 +484,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                     const int t = t0 + u;
                     const double Dn = rec_step(Dv, Ec[u], cc[u]);
                     v[u] = Dn;
-                    const bool zone_end = t == zend0 || t == zend1;
+                    const bool zone_end = zr.ends(t);
                     double x = Dn;
                     if (zone_end && wl) {
                         load_fix(zone_of(t));
@@ -563,7 +558,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
                     const int t = t0 + u;
-                    if (wl && (t == zbeg1 || t == zbeg2)) load_fix(t == zbeg1 ? 1 : 2);
+                    if (wl) { const int zs = zr.starts(t); if (zs) load_fix(zs); }
                     const double Dn = rec_step(Dv, Ec[u], cc[u]);
                     double x = has_small ? rec_add(Dn, Sc[u]) : Dn;
                     if (wl && nfx > 0) {
@@ -573,7 +568,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         x = fixlane ? acc : x;
                     }
                     v[u] = x;
-                    const bool zone_end = t == zend0 || t == zend1;     // the next zone starts from the final row (spec:359,378)
+                    const bool zone_end = zr.ends(t);     // the next zone starts from the final row (spec:359,378)
                     Dv = t < L ? (zone_end ? (stdl ? x : 0.0) : Dn) : Dv;
                     if (valid && t < L) {
                         const int so = t * RB;
@@ -676,7 +671,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
             if (mk == 0) {
                 notfound = true;
                 if (N - 3 > 61 && lane == 0 && t >= 0) {
-                    if (t == zbeg1 || t == zbeg2) s_flag[0] = 1;
+                    if (zr.starts(t)) s_flag[0] = 1;
                     else { flag_row(s_nf, t); s_flag[3] = 1; }
                 }
             }
@@ -707,7 +702,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                 const double Jx = u == 0 ? Jnext : Jc[u - 1];
                 const double src = rec_src(rec_hr(hk, prmu), Jx, Ec[u], Jc[u]);
                 // first row of a zone: attenuate the boundary only (spec:413-419,433-439)
-                cc[u] = (SP && (t == zend0 || t == zend1)) ? 0.0 : src;
+                cc[u] = (SP && zr.ends(t)) ? 0.0 : src;
             }
             if (!SP || FAST) {
                 if (!SP) {
@@ -740,7 +735,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                         const int t = t0 - u;
                         const double Un = rec_step(U, Ec[u], cc[u]);
                         v[u] = Un;
-                        const bool zone_start = t == zbeg1 || t == zbeg2;
+                        const bool zone_start = zr.starts(t) != 0;
                         double x = Un;
                         if (zone_start && w0) x = blend(dir == 0 ? Jc[u] : Un, t);
                         U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
@@ -831,7 +826,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
                     double x = Un;
                     if (w0 && t >= 0) x = blend(dir == 0 ? Jc[u] : Un, t);
                     v[u] = x;
-                    const bool zone_start = t == zbeg1 || t == zbeg2;   // blended row feeds the zone above
+                    const bool zone_start = zr.starts(t) != 0;          // blended row feeds the zone above
                     U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
                     if (valid && t >= 0) {
                         const int so = t * RB;
@@ -970,7 +965,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
         // (one workgroup per column: thread tid < N holds direction tid; split: from the surface row, specular or none)
         const double U0 = SPLIT ? ((act && surface == SOSRT_SURFACE_SPECULAR) ? rho * s_sfc[N - 1 - tid] : 0.0) : Bv;
         __syncthreads();
-        const bool missing = redo_upward_sweep<ACC, SAVED>(L, N, RB, zend0, zend1, zbeg1, zbeg2, s_hd, g.mu, rJ, rE, rIn, rI, rS, U0,
+        const bool missing = redo_upward_sweep<ACC, SAVED, MZ>(L, N, RB, zr, s_hd, g.mu, rJ, rE, rIn, rI, rS, U0,
                                                             s_stage, rup_v, rup_i);
         if (missing) {                                                  // the reference raises IndexError (spec:404)
             if (tid == 0) {
@@ -999,12 +994,12 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 
 inline int scan_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
 template <bool SPLIT>
-inline size_t scan_lds_bytes(const Grid& g) {
+inline size_t scan_lds_bytes(const Grid& g, int nzcap = kRingZones) {
     using C = ScanCfg<SPLIT>;
     const int nwc = SPLIT ? 1 : (g.N + 63) / 64, ncw = nwc * C::SW, nwaves = ncw + NLOAD, ND = (g.N + 63) / 64 * 64;
-    const size_t doubles = (size_t)C::NST * C::STAGE + (size_t)nwc * CR * 64 + ND + (size_t)kRingZones * scan_fixcap(g) * kFixMaxSrc + nwaves + 2 +
+    const size_t doubles = (size_t)C::NST * C::STAGE + (size_t)nwc * CR * 64 + ND + (size_t)nzcap * scan_fixcap(g) * kFixMaxSrc + nwaves + 2 +
                            g.L + 1 + (size_t)g.nsmall * g.L + 16 + 4 * ND + (size_t)ncw * 2 * TC * 16;
-    return doubles * sizeof(double) + ((size_t)(nwc * CR + C::NST + C::NST * nwc + (g.L + 31) / 32) * sizeof(int) + 7) / 8 * 8;
+    return doubles * sizeof(double) + ((size_t)(nwc * CR + C::NST + C::NST * nwc + (g.L + 31) / 32 + kMaxZones) * sizeof(int) + 7) / 8 * 8;
 }
 
 template <bool SPLIT>
@@ -1012,10 +1007,10 @@ void launch_scan_t(hipStream_t s, dim3 grid, const TransportArgs& a) {
     using C = ScanCfg<SPLIT>;
     const int nwc = SPLIT ? 1 : (a.g.N + 63) / 64;
     const dim3 block((nwc * C::SW + NLOAD) * 64);
-    const size_t shm = scan_lds_bytes<SPLIT>(a.g);
-#define SOSRT_SCAN_LAUNCH_N(ACC_, SAVED_, NC_)                                                                 \
+    const size_t shm = scan_lds_bytes<SPLIT>(a.g, a.nzcap);
+#define SOSRT_SCAN_LAUNCH_Z(ACC_, SAVED_, NC_, MZ_)                                                            \
     do {                                                                                                       \
-        auto kern = k_transport_scan<ACC_, SAVED_, SPLIT, NC_>;                                                \
+        auto kern = k_transport_scan<ACC_, SAVED_, SPLIT, NC_, MZ_>;                                           \
         static bool big_lds = false;                                                                           \
         if (!big_lds) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1024,18 +1019,25 @@ void launch_scan_t(hipStream_t s, dim3 grid, const TransportArgs& a) {
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
     } while (0)
-#define SOSRT_SCAN_LAUNCH(ACC_, SAVED_) SOSRT_SCAN_LAUNCH_N(ACC_, SAVED_, 0)
+#define SOSRT_SCAN_LAUNCH_N(ACC_, SAVED_, NC_) SOSRT_SCAN_LAUNCH_Z(ACC_, SAVED_, NC_, false)
+    // (a batch with a column of more than three zones: the instantiation that reads the other boundaries from the descriptors)
+#define SOSRT_SCAN_LAUNCH(ACC_, SAVED_)                                                                        \
+    do {                                                                                                       \
+        if (a.nzcap > kRingZones) SOSRT_SCAN_LAUNCH_Z(ACC_, SAVED_, 0, true);                                  \
+        else SOSRT_SCAN_LAUNCH_Z(ACC_, SAVED_, 0, false);                                                      \
+    } while (0)
     static const bool kFixN = !(getenv("SOSRT_SCAN_NC") && atoi(getenv("SOSRT_SCAN_NC")) == 0);      // (A/B: 0 = the generic instantiation)
     if (a.accumulate) {
         if (a.saved) SOSRT_SCAN_LAUNCH(true, true);
-        else if (SPLIT && kFixN && a.g.N == 128) SOSRT_SCAN_LAUNCH_N(true, false, SPLIT ? 128 : 0);
-        else if (SPLIT && kFixN && a.g.N == 256) SOSRT_SCAN_LAUNCH_N(true, false, SPLIT ? 256 : 0);
+        else if (SPLIT && kFixN && a.nzcap <= kRingZones && a.g.N == 128) SOSRT_SCAN_LAUNCH_N(true, false, SPLIT ? 128 : 0);
+        else if (SPLIT && kFixN && a.nzcap <= kRingZones && a.g.N == 256) SOSRT_SCAN_LAUNCH_N(true, false, SPLIT ? 256 : 0);
         else SOSRT_SCAN_LAUNCH(true, false);
     } else {
         SOSRT_SCAN_LAUNCH(false, false);
     }
 #undef SOSRT_SCAN_LAUNCH
 #undef SOSRT_SCAN_LAUNCH_N
+#undef SOSRT_SCAN_LAUNCH_Z
 }
 
 }  // namespace
@@ -1055,6 +1057,10 @@ bool transport_scan_split_ok(const Grid& g) {
     return scan_lds_bytes<true>(g) <= kScanLdsBytes;
 }
 int transport_scan_parts(const Grid& g) { return (g.N + 63) / 64; }
+// whether the per-zone tables of a batch whose columns have up to nzcap zones still fit beside the stages
+bool transport_scan_fits(const Grid& g, int nzcap, bool split) {
+    return (split ? scan_lds_bytes<true>(g, nzcap) : scan_lds_bytes<false>(g, nzcap)) <= kScanLdsBytes;
+}
 size_t transport_scan_scratch_doubles() { return kScanScratch; }
 
 // a.scan_split: two workgroups per column (the grid is then twice the columns; specular surface or none; a.scan_scratch /

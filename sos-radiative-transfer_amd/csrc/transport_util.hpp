@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kernels.hpp"
+
 namespace sosrt {
 namespace {
 
@@ -108,6 +110,70 @@ __device__ __forceinline__ double blend_val(double w, double r0, double rk) {
 //   In_limit:113-141 as a linear map: acc + c x
 __device__ __forceinline__ double fix_acc(double c, double x, double acc) { return __builtin_fma(c, x, acc); }
 
+// ---- the zone table as the sweeps look at it -------------------------------------------------------------------------------
+// Which rows end a zone that has another below it, which rows start a zone other than the first, which zone a row is in.  The
+// reference's three zones (spec:113-449) are two boundaries held in scalars -- the sweeps of a (clear, slab, clear) column
+// execute exactly what they did when the kernels knew nothing else --; the boundaries of a column with more aerosol layers
+// (up to kMaxZones zones) are read from its descriptor, in the chunks that contain one only.
+// (MZ: the kernel instantiation for batches that hold a column of more than three zones; without it the tests of the other
+// boundaries are not compiled at all)
+template <bool MZ> struct ZoneRows {
+    const ColDesc* dg;
+    int nz, zend0, zend1, zbeg1, zbeg2;
+    int zb[MZ ? kMaxZones : 1];       // MZ: first rows of zones 3 .. (indices below 3 unused), -99 past the last zone: scalars too
+    __device__ __forceinline__ explicit ZoneRows(const ColDesc* d) : dg(d) {
+        nz = d->nz;
+        zend0 = nz > 1 ? d->r1[0] : -9; zend1 = nz > 2 ? d->r1[1] : -9;
+        zbeg1 = nz > 1 ? d->r0[1] : -9; zbeg2 = nz > 2 ? d->r0[2] : -9;
+        if constexpr (MZ) {
+#pragma unroll
+            for (int k = 3; k < kMaxZones; ++k) zb[k] = k < nz ? d->r0[k] : -99;
+        }
+    }
+    __device__ __forceinline__ bool ends(int t) const {           // last row of a zone that is followed by another
+        bool e = t == zend0 || t == zend1;
+        if constexpr (MZ) {
+#pragma unroll
+            for (int k = 3; k < kMaxZones; ++k) e = e || t == zb[k] - 1;
+        }
+        return e;
+    }
+    __device__ __forceinline__ int starts(int t) const {          // the zone (>= 1) whose first row is t, 0 if none
+        int z = t == zbeg1 ? 1 : (t == zbeg2 ? 2 : 0);
+        if constexpr (MZ) {
+#pragma unroll
+            for (int k = 3; k < kMaxZones; ++k) z = t == zb[k] ? k : z;
+        }
+        return z;
+    }
+    __device__ __forceinline__ int of(int t) const {              // the zone of row t (t may differ between lanes)
+        int z = (zbeg2 >= 0 && t >= zbeg2) ? 2 : ((zbeg1 >= 0 && t >= zbeg1) ? 1 : 0);
+        if constexpr (MZ) {
+#pragma unroll
+            for (int k = 3; k < kMaxZones; ++k) z = (zb[k] >= 0 && t >= zb[k]) ? k : z;
+        }
+        return z;
+    }
+    __device__ __forceinline__ int nfix(int zz) const { return dg->nfix[zz]; }
+    // bit q of the result: chunk q of a sweep (TC rows; up: counted from the last row) contains a zone boundary
+    __device__ __forceinline__ unsigned long long boundary_chunks(int L, int tc, bool up) const {
+        unsigned long long m = 0;
+        if constexpr (!MZ) {
+            const int rows[4] = {zend0, zend1, zbeg1, zbeg2};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (rows[i] >= 0) m |= 1ull << ((up ? L - 1 - rows[i] : rows[i]) / tc);
+        } else {
+            for (int k = 1; k < nz; ++k) {
+                const int rb = dg->r0[k], re = rb - 1;            // first row of zone k, last row of zone k - 1
+                m |= 1ull << ((up ? L - 1 - rb : rb) / tc);
+                m |= 1ull << ((up ? L - 1 - re : re) / tc);
+            }
+        }
+        return m;
+    }
+};
+
 // ---- rows of the upward sweep whose mu -> 0+ search leaves the first wave ------------------------------------------------
 // spec:403-406 has no bound: `while |second difference| > 1e-4: idx++`.  The sweeps test the candidates that fit the first
 // wave of a row (lanes 1 .. 61); a row with no stop there is left RAW in memory (nothing blended: kf = 1) and flagged in an LDS
@@ -205,8 +271,8 @@ __device__ SOSRT_HELPER_INLINE bool finish_flagged_rows(const int* s_nf, int L, 
 // 650 us for a 200-row column that the rest of its launch then waited for).
 // s_work: kRedoRows-independent, 2 N + 4 doubles.  Returns true if some row has no stop at all (IndexError, spec:404).
 constexpr int kRedoRows = 8;
-template <bool ACC, bool SAVED>
-__device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, int zend0, int zend1, int zbeg1, int zbeg2, const double* s_hd,
+template <bool ACC, bool SAVED, bool MZ>
+__device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, const ZoneRows<MZ>& zr, const double* s_hd,
                                   const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rJ, __amdgpu_buffer_rsrc_t rE,
                                   __amdgpu_buffer_rsrc_t rIn, __amdgpu_buffer_rsrc_t rI, __amdgpu_buffer_rsrc_t rS, double U0,
                                   double* s_work, double& rup_v, double& rup_i) {
@@ -239,7 +305,7 @@ __device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, int 
             if (t < 0) break;                                           // (uniform)
             double* row = s_row + par * (N + 2);
             const double src = rec_src(rec_hr(s_hd[t + 1], prmu), Jnext, Ec[u], Jc[u]);
-            const double Un = rec_step(U, Ec[u], (t == zend0 || t == zend1) ? 0.0 : src);   // first row of a zone: attenuate only (H4)
+            const double Un = rec_step(U, Ec[u], zr.ends(t) ? 0.0 : src);   // first row of a zone: attenuate only (H4)
             if (act) row[j] = tid == 0 ? Jc[u] : Un;                    // spec:401
             __syncthreads();
             if (act && j >= 1 && j <= N - 3 && !(fabs((row[j] - row[j + 1]) - (row[j + 1] - row[j + 2])) > 0.0001)) atomicMin(&s_kf[par], j);
@@ -250,7 +316,7 @@ __device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, int 
             const int kf = ks == (1 << 30) ? 1 : ks + 1;
             double x = act ? row[j] : 0.0;
             if (tr && tid < kf) x = blend_val(blend_weight(mu, 1.0 / gmu[N + kf]), row[0], row[kf]);
-            const bool zone_start = t == zbeg1 || t == zbeg2;           // blended row feeds the zone above (H5)
+            const bool zone_start = zr.starts(t) != 0;                  // blended row feeds the zone above (H5)
             U = (zone_start && tr) ? x : Un;
             Jnext = Jc[u];
             if (act) {

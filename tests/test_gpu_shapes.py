@@ -415,9 +415,10 @@ def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
 
 
 def test_three_zone_columns_keep_their_bits_beside_columns_of_more_zones():
-    """A batch that mixes (clear, slab, clear) columns with two-layer columns: the latter go through the general transport
-    kernel, the former keep the ring / chunk-parallel kernel (two launches per order, each skipping the other's columns), so
-    a three-zone column has the bits it has in a batch of its own; the two-layer column matches the oracle."""
+    """A batch that mixes (clear, slab, clear) columns with two-layer columns: the batch takes the zone-table instantiation of
+    the ring / chunk-parallel kernels (the boundaries beyond the reference's two held in scalars as well), whose arithmetic for a
+    three-zone column is the three-zone instantiation's: such a column has the bits it has in a batch of its own; the two-layer
+    column matches the oracle."""
     L, N = 48, 64
     mu = inputs.direction_grid(N)
     P0a, Pa = inputs.phase_function("rayleigh", N, mu, 0.6)
@@ -561,9 +562,9 @@ def test_float_contraction_is_an_opt_in_that_misses_the_parity_bar():
 
 def test_zone_table_columns():
     """columns described by a zone table.  (clear, slab, clear) through sosrt_set_columns_zones equals
-    sosrt_set_columns bit for bit; columns with two aerosol layers (five zones, general transport kernel, dense tiling of
-    the contraction) match the oracle's zone-table path, fluxes and heating rate included (the 'erase_pics' fix-up at
-    both layers).  More than one slab is parity unpinned by construction (the reference has one)."""
+    sosrt_set_columns bit for bit; columns with two aerosol layers (five zones; the ring / chunk-parallel kernels in their
+    zone-table instantiation, every transport mode in the randomised test below) match the oracle's zone-table path, fluxes and
+    heating rate included (the 'erase_pics' fix-up at both layers).  More than one slab is parity unpinned by construction (the reference has one)."""
     L, N, B = 48, 64, 5
     mu = inputs.direction_grid(N)
     P0a, Pa = inputs.phase_function("rayleigh", N, mu, 0.6)
@@ -637,3 +638,5 @@ def test_randomised_parity_across_transport_kernels():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     assert fuzz_parity.run(cases=14, seed=20251005, verbose=False) == 0
+    # columns of two or three aerosol layers (five / seven zones) through the same kernels, against the oracle's zone tables
+    assert fuzz_parity.run_layers(cases=6, seed=20251005, verbose=False) == 0

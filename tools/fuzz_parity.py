@@ -5,6 +5,8 @@ long in some rows and orders and short in others: rows finished one by one, the 
 zone is hit, the transposed fast path elsewhere -- through the ring kernel, the chunk-parallel kernel (one workgroup and
 ceil(N/64) workgroups per column) and the general kernel: ring == chunk-parallel bit for bit, every kernel against the oracle at
 1e-10 with equal order counts (or IndexError where the oracle raises it).
+run_layers: the same for columns with two or three aerosol layers (five or seven zones) against the oracle's
+zone-table path (parity unpinned by construction: the reference has one layer).
     python3 tools/fuzz_parity.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +15,7 @@ for p in ("sos-radiative-transfer_amd", "oracle", "tests"):
 import numpy as np
 import sos_oracle as O
 from sosrt import main as M
-from sosrt.main import SOS_Aer_batch
+from sosrt.main import SOS_Aer_batch, SOS_Aer_layers
 from util import rel_err
 
 MODES = (("ring", {"SOSRT_TRANSPORT": "ring"}), ("scan", {"SOSRT_TRANSPORT": "scan"}),
@@ -100,9 +102,86 @@ def run(cases=24, seed=1, verbose=True):
     return bad
 
 
+def _reset(env):
+    for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_SPLIT"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+
+
+def run_layers(cases=8, seed=1, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(cases):
+        N = int(rng.choice([64, 100, 128, 128, 192, 256]))
+        L = int(rng.integers(40, 120))
+        nsl = int(rng.choice([2, 2, 3]))
+        # layer tops and bottoms from the top of the atmosphere down, clear air between them
+        edges = np.sort(rng.uniform(6, 112, 2 * nsl))[::-1]
+        slabs = [(float(edges[2 * i]), float(edges[2 * i + 1]), float(rng.choice([0.02, 0.1, 0.4, 1.0])), float(rng.uniform(0.8, 1.0))) for i in range(nsl)]
+        surface = str(rng.choice(["specular", "specular", "lambertian_readme"]))
+        B = 3
+        mu0 = rng.uniform(0.15, 1.0, B); rho = rng.uniform(0.0, 0.8, B)
+        J = int(rng.choice([0, 20, 50, 66, 70, 90])); amp = float(rng.choice([0.003, 0.02, 0.3]))
+        mu = O.make_mu(N)
+        c = np.ones(2 * N)
+        c[N:] = np.where(np.arange(N) < J, 1 + amp * (-1.0) ** np.arange(N), 1.0)
+        P_atm = O.phase_rayleigh(N, mu, 0.5)[1] * c[:, None]
+        P_aer = O.phase_hg(N, mu, 0.5, 0.7)[1] * c[:, None]
+        try:
+            cols = [O.make_column_slabs(mu0[b], 120, slabs, L, 0.124, rho[b], 1.0, N, O.phase_rayleigh(N, mu, mu0[b])[0], P_atm,
+                                        O.phase_hg(N, mu, mu0[b], 0.7)[0], P_aer, surface=surface) for b in range(B)]
+        except AssertionError as e:             # layers that touch on this grid
+            if verbose:
+                print("layers case %2d L=%3d N=%3d: %s" % (case, L, N, e))
+            continue
+        out = {}
+        for tag, env in MODES:
+            if tag == "scan1" and N > 128:
+                continue
+            _reset(env)
+            out[tag] = SOS_Aer_layers(mu0, rho, slabs, tauStar_atm=0.124, nb_layers=L, nb_angles=N, aer_phase_fun="hg", g_aer=0.7,
+                                      P_atm=P_atm, P_aer=P_aer, surface=surface, max_orders=150, raise_on_error=False)
+        ring = out["ring"]
+        msg = []
+        for tag in ("scan", "scan1"):
+            r = out.get(tag)
+            if r is not None and not (np.array_equal(r.n, ring.n) and np.array_equal(r.status, ring.status)
+                                      and np.array_equal(r.I[ring.status == 0], ring.I[ring.status == 0])):
+                msg.append("%s differs from ring in bits" % tag)
+        worst = 0.0
+        for b in range(B):
+            try:
+                ref = O.solve_column(cols[b], literal=False, max_orders=150)
+            except IndexError:
+                for tag in out:
+                    if out[tag].status[b] != 1:
+                        msg.append("%s column %d: oracle raises IndexError, status %d" % (tag, b, out[tag].status[b]))
+                continue
+            for tag in out:
+                r = out[tag]
+                if r.status[b] == 2 and ref.n >= 150:
+                    continue
+                if r.status[b] != 0 or r.n[b] != ref.n:
+                    msg.append("%s column %d: status %d n %d (oracle %d)" % (tag, b, r.status[b], r.n[b], ref.n))
+                    continue
+                e = rel_err(r.I[b], ref.I)
+                worst = max(worst, e)
+                if not e <= 1e-10:
+                    msg.append("%s column %d: rel err %.2e" % (tag, b, e))
+        bad += bool(msg)
+        if verbose or msg:
+            print("layers case %2d L=%3d N=%3d %-17s zones %d J=%2d amp=%.3f  orders %s  max rel err %.1e  %s" % (
+                case, L, N, surface, 2 * nsl + 1, J, amp, ring.n.tolist(), worst, "; ".join(msg) if msg else "ok"))
+    _reset({})
+    return bad
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    b = run(n, seed)
+    b = run(n, seed) + run_layers(max(n // 2, 1), seed)
     print("cases with a mismatch:", b)
     sys.exit(1 if b else 0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""What the slow paths cost: a batch of two-layer (five-zone) columns -- general transport kernel, dense-only contraction tiling --
-against the same batch with one layer (three zones: ring / chunk-parallel kernels, live-column tilings).  python3 tools/time_zones.py [B]"""
+"""What more zones cost: a batch of two-layer (five-zone) columns -- the zone-table instantiation of the ring / chunk-parallel
+kernels; round 2: the general kernel, 2.16 vs 0.50 ms at 64 columns -- against the same batch with one layer (three zones).  python3 tools/time_zones.py [B]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sos-radiative-transfer_amd"))
