@@ -587,51 +587,100 @@ void launch_first_order(hipStream_t s, const Grid& g, int B, const double* tau, 
 // improved_asymptotic_downward_radiance (In_limit:70-109) for one (layer, lane): the slice is
 // zone-local [zs, t] (spec:334,353,372).
 // ------------------------------------------------------------------------------------------
-__device__ double small_mu_value(const double* __restrict__ J, size_t jstride, const double* __restrict__ tau, int zs,
-                                 int t, double mu) {
-    const double Jt = J[(size_t)t * jstride];
-    if (fabs(mu) < kMuVerySmall) {                            // both Taylor branches (In_limit:79-93)
-        double slope = 0.0;
-        if (t > zs) slope = (Jt - J[(size_t)(t - 1) * jstride]) / (tau[t] - tau[t - 1]);
-        return -Jt + mu * slope;
-    }
-    const double tt = tau[t];
-    const double lim = tt - 5 * fabs(mu);                     // In_limit:97-98
-    if (!(tt >= lim)) return -Jt;                             // empty window
-    double acc = 0, fprev = Jt * exp((tt - tt) / mu);
-    bool bad = !isfinite(fprev);
-    for (int s = t - 1; s >= zs && tau[s] >= lim; --s) {
-        const double f = J[(size_t)s * jstride] * exp((tt - tau[s]) / mu);
-        bad = bad || !isfinite(f);
-        acc += (tau[s + 1] - tau[s]) * (fprev + f) / 2;
-        fprev = f;
-    }
-    if (bad) return -Jt;                                      // In_limit:104-105
-    return -acc / mu;
-}
-
-__global__ void k_smallmu(Grid g, const double* __restrict__ tau_all, const double* __restrict__ Jn_all,
-                          double* __restrict__ In_all, const ColDesc* __restrict__ desc,
-                          const int* __restrict__ active) {
-    const int b = blockIdx.z;
+// k_smallmu: workgroups per (column, small lane, block of rows): the lane's L values of J (2 N doubles apart in memory) and
+// the column's optical depths are staged in LDS once, then kSmallP threads share the window [tau_t - 5 |mu|, tau_t] of row t -- up
+// to ~64 rows at N = 128, each an fp64 exponential; thread q takes the rows t-1-q, t-1-q-kSmallP, ... and receives the neighbouring
+// integrand from the thread beside it, so every exponential is evaluated once; the partial trapezoid sums are added at the
+// end.  (Until round 3 one thread walked the whole window in global memory, a chain of ~64 dependent strided loads and
+// exponentials: 25 us per order for 64 columns, as long as the transport of the same order; now 7.)
+constexpr int kSmallP = 8;              // threads per row
+constexpr int kSmallRows = 256 / kSmallP;
+__global__ __launch_bounds__(256) void k_smallmu(Grid g, const double* __restrict__ tau_all, const double* __restrict__ Jn_all,
+                                                 double* __restrict__ In_all, const ColDesc* __restrict__ desc,
+                                                 const int* __restrict__ active) {
+    const int b = blockIdx.y;
     if (active && !active[b]) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.L) return;
-    const int m = g.small_lanes[blockIdx.y];
+    const int m = g.small_lanes[blockIdx.x];
     const ColDesc& d = desc[b];
-    int z = 0;
-    while (z + 1 < d.nz && t > d.r1[z]) ++z;
-    if (m >= g.N - d.nfix[z]) return;                        // rewritten by the extrapolation anyway
+    bool any = false;                                          // rewritten by the extrapolation in every zone: nothing to do
+    for (int z = 0; z < d.nz; ++z) any = any || m < g.N - d.nfix[z];
+    if (!any) return;
+    extern __shared__ double sm_small[];
+    double* s_tau = sm_small;                                  // [L]
+    double* s_J = s_tau + g.L;                                 // [L]
     const double* tau = tau_all + (size_t)b * g.L;
     const double* J = Jn_all + (size_t)b * g.L * g.D + m;
-    In_all[((size_t)b * g.L + t) * g.D + m] = small_mu_value(J, g.D, tau, d.r0[z], t, g.mu[m]);
+    for (int t = threadIdx.x; t < g.L; t += blockDim.x) {
+        s_tau[t] = tau[t];
+        s_J[t] = J[(size_t)t * g.D];
+    }
+    __syncthreads();
+    const double mu = g.mu[m];
+    const int q = threadIdx.x & (kSmallP - 1);
+    for (int t0 = blockIdx.z * kSmallRows; t0 < g.L; t0 += gridDim.z * kSmallRows) {     // (uniform trip count: shuffles inside)
+        const int t = t0 + threadIdx.x / kSmallP;
+        const bool row = t < g.L;
+        const int tc = row ? t : g.L - 1;
+        int z = 0;
+        while (z + 1 < d.nz && tc > d.r1[z]) ++z;
+        const int zs = d.r0[z];
+        const bool wanted = row && m < g.N - d.nfix[z];          // else rewritten by the extrapolation anyway
+        const double Jt = s_J[tc], tt = s_tau[tc];
+        double val;
+        if (fabs(mu) < kMuVerySmall) {                            // both Taylor branches (In_limit:79-93)
+            double slope = 0.0;
+            if (tc > zs) slope = (Jt - s_J[tc - 1]) / (tt - s_tau[tc - 1]);
+            val = -Jt + mu * slope;
+        } else {
+            const double lim = tt - 5 * fabs(mu);                 // In_limit:97-98
+            double acc = 0;
+            double fcarry = Jt * exp((tt - tt) / mu);             // integrand at the row above this round's first (thread 0's neighbour)
+            bool bad = !isfinite(fcarry);
+            bool alive = wanted;
+            const int gsh = (threadIdx.x & 63) & ~(kSmallP - 1);
+            // round j: thread q evaluates row sq = t - 1 - q - kSmallP j; rows are taken while s >= zs and tau[s] >= lim (the
+            // reference's slice ends at the first row that fails: a thread's row counts only if the rows before it did)
+            for (int j = 0;; ++j) {
+                const int sq = tc - 1 - q - kSmallP * j;
+                const int sc = sq < 0 ? 0 : sq;
+                const bool mine = alive && sq >= zs && s_tau[sc] >= lim;
+                const unsigned long long bal = __ballot(mine);
+                if (bal == 0) break;
+                const unsigned grp = (unsigned)(bal >> gsh) & ((1u << kSmallP) - 1);
+                const unsigned upto = (2u << q) - 1;
+                const bool ok = (grp & upto) == upto;
+                alive = grp == (1u << kSmallP) - 1;
+                const double f = ok ? s_J[sc] * exp((tt - s_tau[sc]) / mu) : 0.0;
+                double fup = __shfl_up(f, 1, kSmallP);             // the integrand one row below in the sum's order (s + 1)
+                if (q == 0) fup = fcarry;
+                if (ok) {
+                    bad = bad || !isfinite(f);
+                    acc += (s_tau[sc + 1] - s_tau[sc]) * (fup + f) / 2;
+                }
+                fcarry = __shfl(f, kSmallP - 1, kSmallP);
+            }
+#pragma unroll
+            for (int o = 1; o < kSmallP; o <<= 1) acc += __shfl_xor(acc, o, kSmallP);
+            int badi = bad;
+#pragma unroll
+            for (int o = 1; o < kSmallP; o <<= 1) badi |= __shfl_xor(badi, o, kSmallP);
+            bad = badi != 0;
+            val = (!(tt >= lim) || bad) ? -Jt : -acc / mu;        // empty window, In_limit:104-105
+        }
+        if (wanted && q == 0) In_all[((size_t)b * g.L + t) * g.D + m] = val;
+    }
 }
 
 void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
                     const ColDesc* desc, const int* active) {
     if (g.nsmall <= 0) return;
-    dim3 grid((g.L + 63) / 64, g.nsmall, B);
-    hipLaunchKernelGGL(k_smallmu, grid, dim3(64), 0, s, g, tau, Jn, In, desc, active);
+    const size_t shm = 2 * (size_t)g.L * sizeof(double);
+    if (shm > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k_smallmu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    // row blocks: enough workgroups for four per CU
+    int nblk = (1024 + g.nsmall * B - 1) / (g.nsmall * B);
+    const int most = (g.L + kSmallRows - 1) / kSmallRows;
+    nblk = nblk < 1 ? 1 : (nblk > most ? most : nblk);
+    hipLaunchKernelGGL(k_smallmu, dim3(g.nsmall, B, nblk), dim3(256), shm, s, g, tau, Jn, In, desc, active);
 }
 
 // ------------------------------------------------------------------------------------------
