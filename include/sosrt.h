@@ -61,7 +61,9 @@ int sosrt_version(void);
 /* ---- handle ------------------------------------------------------------------------------- */
 /* L = nb_layers, N = nb_angles per hemisphere (spec:33,57).  Buffers are sized for max_batch
  * columns; max_orders bounds the order loop of spec:309.  device < 0 makes a host-only handle
- * (plan queries only, no GPU is touched). */
+ * (plan queries only, no GPU is touched).  4 <= N <= 1024; 2 <= L, and three values per layer of a column must fit the
+ * 64 KiB of LDS the first-order kernel asks for (L <= 2686 at N = 128; the reference ships L = 800): SOSRT_E_INVALID
+ * otherwise, with the largest L in sosrt_last_error(). */
 int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_t** out);
 int sosrt_destroy(sosrt_t* h);
 /* Streams.  A new handle enqueues on a stream of its own, created as a BLOCKING stream (hipStreamDefault): it orders against

@@ -414,6 +414,13 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (N < 4) return fail(SOSRT_E_INVALID, "nb_angles must be >= 4 (got %d)", N);
     if (N > 1024) return fail(SOSRT_E_INVALID, "nb_angles must be <= 1024 (got %d)", N);
     if (max_batch < 1 || max_orders < 1) return fail(SOSRT_E_INVALID, "max_batch and max_orders must be >= 1");
+    {   // the first-order kernel keeps three values per layer of its column in LDS (the largest per-layer need of any kernel)
+        const int nt = (N + 63) / 64 * 64;
+        const size_t need = (size_t)(3 * (size_t)L + nt + nt / 64 + 4) * sizeof(double);
+        if (need > 64 * 1024)
+            return fail(SOSRT_E_INVALID, "nb_layers = %d does not fit: at most %d layers at nb_angles = %d", L,
+                        (int)((64 * 1024 / sizeof(double) - nt - nt / 64 - 4) / 3), N);
+    }
     sosrt_handle* h = new (std::nothrow) sosrt_handle();
     if (!h) return fail(SOSRT_E_NOMEM, "out of host memory");
     h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;

@@ -70,6 +70,9 @@ def test_argument_errors():
         Solver(1, 32, device=-1)
     with pytest.raises(ValueError):
         Solver(10, 2, device=-1)
+    with pytest.raises(ValueError, match="at most 2686 layers"):      # three values per layer in the LDS of the first-order kernel
+        Solver(2687, 128, device=-1)
+    Solver(2686, 128, device=-1).close()
     s = Solver(10, 8, device=-1)
     with pytest.raises(ValueError):
         s.set_grid(np.zeros(15))
