@@ -24,7 +24,9 @@ No collective runs inside the order loop.
 Prints ONE JSON line on rank 0 (see the contract in the task description).  Beside the headline (N = 1 only, outside its
 timed region, `--no-extras` skips them): `extras.c2` / `extras.c3` = one EVA column at N_mu = 128 / 256 (BASELINE
 configs[1], [2]: single-column latency), `extras.c5` = the 4096-column wildfire sweep at L = 400, N = 256 (configs[4]),
-each with its own check against the oracle.
+each with its own check against the oracle.  `--groups 1` (default) runs the headline's order loop as one column group on one
+stream, so that every kernel is timed alone on the GPU (the roofline objects are per kernel); the library by itself takes two
+groups on two streams for a batch of this size, which is faster: `two_groups` holds that measurement (same sweep, same bits).
 """
 import argparse
 import json
@@ -305,6 +307,12 @@ def main():
     ap.add_argument("--aerosol", choices=tuple(SCENARIOS), default="eva")
     ap.add_argument("--max-orders", type=int, default=256)
     ap.add_argument("--inflight", type=int, default=1, help="independent solves in flight (own handle + stream each)")
+    ap.add_argument("--groups", choices=("1", "2", "auto"), default="1",
+                    help="column groups of the order loop in the headline's timed region (SOSRT_GROUPS).  1 (default): one stream, "
+                         "every kernel has the GPU to itself, so the per-kernel roofline below is what the kernel does; auto: the "
+                         "library's own choice (two groups on two streams for a batch of this size: contraction and transport of "
+                         "the halves side by side, faster, per-launch durations no longer those of a kernel alone) -- measured "
+                         "beside the headline as `two_groups`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / C3 / C5 figures beside the headline")
     ap.add_argument("--pipelined", type=int, default=3,
@@ -386,6 +394,10 @@ def main():
     # the order loop of a sweep ends in a long tail of launches over its few slowest-converging
     # columns, which leaves most CUs idle; the next sweep's dense launches fill them.
     torch.cuda.synchronize(dev)
+    if a.groups == "auto":
+        os.environ.pop("SOSRT_GROUPS", None)
+    else:
+        os.environ["SOSRT_GROUPS"] = a.groups                     # (read by sosrt_create)
     lanes = [Lane(w, dev, local_rank, a.max_orders)]
     while len(lanes) < max(1, a.inflight):
         lanes.append(Lane(w, dev, local_rank, a.max_orders, lanes[0].shared()))
@@ -518,6 +530,30 @@ def main():
         pipe = {"steps_in_flight": a.pipelined, "steps": psteps, "value": B * psteps / dtp, "unit": "columns/s",
                 "ms_per_step": dtp / psteps * 1e3}
 
+    # Beside the headline too: the same sweep with the order loop the library chooses by itself for a batch of this size -- two
+    # column groups on two streams -- one step at a time; the field must have the headline's bits.
+    two = None
+    if world == 1 and a.groups == "1" and not a.no_extras:
+        os.environ.pop("SOSRT_GROUPS", None)
+        l2 = Lane(w, dev, local_rank, a.max_orders, lanes[0].shared())
+        os.environ["SOSRT_GROUPS"] = a.groups
+        try:
+            for _ in range(2):
+                l2.solve()
+            torch.cuda.synchronize(dev)
+            tsteps = max(a.steps, 10)
+            t20 = time.perf_counter()
+            for _ in range(tsteps):
+                l2.solve()
+            torch.cuda.synchronize(dev)
+            dt2 = (time.perf_counter() - t20) / tsteps
+            two = {"order_loop": "SOSRT_GROUPS unset: the library's choice (two column groups on two streams while one field of the "
+                                 "batch is between 128 and 512 MB)", "steps": tsteps, "ms_per_step": dt2 * 1e3,
+                   "value": B / dt2, "unit": "columns/s",
+                   "same_bits_as_headline": bool(torch.equal(l2.I, lanes[0].I) and torch.equal(l2.n, lanes[0].n))}
+        finally:
+            l2.close()
+
     cpu_t = dev if on_gpu else "cpu"
     t = torch.tensor([dt], dtype=torch.float64, device=cpu_t)
     per_rank = torch.zeros(world, 2, dtype=torch.float64, device=cpu_t)
@@ -561,6 +597,10 @@ def main():
                        "max_order": int(n_host.max()),
                        "not_converged": int((st_host != 0).sum()), "inflight_solves": max(1, a.inflight),
                        "p0": "built on the device (sosrt_phase_p0_dev), outside the timed region",
+                       "order_loop": {"1": "one column group, one stream (SOSRT_GROUPS=1): no kernel runs beside another; the library "
+                                           "alone takes two groups at this size: `two_groups`",
+                                      "2": "two column groups on two streams (SOSRT_GROUPS=2)",
+                                      "auto": "the library's choice (SOSRT_GROUPS unset)"}[a.groups],
                        "gather": ({"digest": "digest (TOA / surface rows, order counts) to rank 0 once per step, torch.distributed gather",
                                    "field": "whole fields to rank 0 once per step, ragged point-to-point blocks (torch.distributed)",
                                    "abi": "whole fields to rank 0 once per step through the C ABI (sosrt_gather: ncclSend / ncclRecv)"}[a.gather])
@@ -617,12 +657,15 @@ def main():
                                 "peaks": "%.1f TFLOP/s FP64 matrix, %.0f GB/s HBM" % (FP64_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS)}
         if pipe:
             out["pipelined"] = pipe
+        if two:
+            out["two_groups"] = two
         if world == 1 and not a.no_extras:
             # the other single-GPU configurations of BASELINE.json, outside the headline's timed region
             for ln in lanes:
                 ln.close()
             lanes.clear()
             torch.cuda.empty_cache()
+            os.environ.pop("SOSRT_GROUPS", None)          # (one column, or a 6.7-GB field: one group either way)
             ex = {}
             try:
                 ex["c2"] = extra_case(O, dev, local_rank, 1, 200, 128, "eva", 20, [0])

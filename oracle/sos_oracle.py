@@ -368,6 +368,25 @@ def first_order(c: Column) -> np.ndarray:
     return I1
 
 
+def first_order_extended(c: Column) -> np.ndarray:
+    """`first_order` with every intermediate in numpy's long double (x86-64: 64-bit mantissa) on the same float64 inputs,
+    rounded to float64 once at the end.  Not a second oracle: a yardstick for the ROUNDING NOISE of the reference's own
+    arithmetic.  spec:113-292 divides a difference of exponentials by (mu0 + mu) and switches to the limit form only within
+    |mu0 - |mu|| < 1e-4 (spec:126,...): a direction that lies just outside that window (say 1.6e-4 from mu0) carries the
+    rounding of the two exponentials amplified by mu0 / 1.6e-4 = 5000 -- a few 1e-13 absolute, up to 2e-10 relative to a
+    small element -- in the reference itself.  A float64 implementation that does not replay the reference's exact sequence
+    of roundings (numpy's exp included) cannot agree with it more closely than that there; tools/fuzz_parity.py and
+    tests/test_gpu_parity.py compare both against this evaluation when a column has such a direction."""
+    import copy
+    ld = np.longdouble
+    c2 = copy.copy(c)
+    for k in ("tau", "mu", "P0_atm", "P0_aer"):
+        setattr(c2, k, np.asarray(getattr(c, k)).astype(ld))
+    for k in ("mu0", "grd_alb", "alb_atm", "alb_aer", "dtau_atm", "dtau_aer", "tauStar_tot"):
+        setattr(c2, k, ld(getattr(c, k)))
+    return np.asarray(first_order(c2), dtype=np.float64)
+
+
 def first_order_lambertian_readme(c: Column) -> np.ndarray:
     """First order over a Lambertian surface as the reference's README writes it (README.md:126-171).  PARITY UNPINNED: the
     reference ships no runnable code for it -- `lam:274-276` crashes and the other first-order blocks of that

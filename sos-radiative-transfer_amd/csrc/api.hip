@@ -65,7 +65,7 @@ struct sosrt_handle {
     static constexpr int kMaxGroups = 2;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int ngroups = 1, want_groups = 1, split_min = 256;
+    int ngroups = 1, want_groups = 0, split_min = 256;      // want_groups 0: by the size of the batch's field (set_columns)
     int split_at = -1;                   // SOSRT_GROUP_SPLIT: first column of the second group (default: the middle)
     int prio2 = 0;                       // SOSRT_GROUP_PRIO: the internal stream is created with the highest priority
     int coresident_pad = 27008;         // SOSRT_GEMM_PAD_LDS: 27 656 static + this > 1/3 of 160 KiB
@@ -435,7 +435,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_SCAN_SPLIT")) h->scan_split = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
-    if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : 1;      // column groups of the order loop
+    if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : (atoi(ev) == 1 ? 1 : 0);      // column groups of the order loop (0: auto)
     if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
     if (const char* ev = getenv("SOSRT_STAGGER")) h->stagger = atof(ev);
     if (const char* ev = getenv("SOSRT_GROUP_SPLIT")) h->split_at = atoi(ev);
@@ -722,7 +722,17 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
     std::vector<int> slab, plain, iup(B, 0), idn(B, 0);
     auto zone_end = [&](int b, int z) { return z + 1 < nz[b] ? zr0[b * kMaxZones + z + 1] - 1 : L - 1; };
     // column groups of the order loop: two contiguous halves for a large batch
-    h->ngroups = (h->want_groups >= 2 && B >= h->split_min && B >= 2) ? 2 : 1;
+    // (auto: two groups while one field of the batch, B L D doubles, is between 128 and 512 MB -- measured, round 3, EVA / wildfire
+    // sweeps with one and two groups alternating on one box: 384 x (200, 128) 4.05 -> 3.74 ms, 512 x (200, 128) 5.03 -> 4.78,
+    // 1024 x (200, 128) 9.2 -> 8.85, 512 x (200, 256) 13.1 -> 12.65; 256 x (200, 128) and 512 x (200, 64) unchanged; 512 x (400, 256)
+    // 13.35 -> 14.2, 4096 x (200, 128) 32.8 -> 34.8, 4096 x (400, 256) 100 -> 106: the halves' source function and radiance stay in
+    // the 256-MB memory-side cache between the contraction and the transport only when they are that small)
+    int want = h->want_groups;
+    if (want == 0) {
+        const double field_mb = (double)B * L * h->D * sizeof(double) / (1024.0 * 1024.0);
+        want = (field_mb > 128.0 && field_mb <= 512.0) ? 2 : 1;
+    }
+    h->ngroups = (want >= 2 && B >= h->split_min && B >= 2) ? 2 : 1;
     h->gb[0] = 0; h->gb[1] = h->ngroups == 2 ? ((h->split_at > 0 && h->split_at < B) ? h->split_at : B / 2) : B; h->gb[2] = B;
     for (int k = 0; k <= sosrt_handle::kMaxGroups; ++k) { h->main_off[k] = 0; h->slab_off[k] = 0; }
     h->max_nz = 1;

@@ -56,6 +56,20 @@ def test_bench_extras_c2_c3_c5_and_hg_stand_in():
         assert e["check"]["ok"] and e["check"]["max_rel_err_vs_oracle"] <= 1e-10 and e["not_converged"] == 0, (k, e)
         assert ("%d column" % cols) in e["workload"] and ("N=%d" % N) in e["workload"] and e["columns_per_s"] > 0
     assert ex["c5"]["columns_per_s"] > 10 * ex["c3"]["columns_per_s"]          # a batch fills the GPU, a lone column cannot
+    # beside the headline (one column group, every kernel alone): the library's own order loop for the batch, same bits
+    assert "one column group" in d["config"]["order_loop"]
+    assert d["two_groups"]["same_bits_as_headline"] and d["two_groups"]["value"] > 0
+
+
+def test_bench_two_column_groups_at_the_headline_size():
+    """512 columns at (200, 128): the library takes two column groups by itself (one field of the batch = 210 MB); `two_groups`
+    measures that loop beside the one-group headline and must find the headline's bits."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pipelined", "0",
+                        "--check-columns", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["check"]["ok"] and d["two_groups"]["same_bits_as_headline"]
+    assert 0.7 < d["two_groups"]["ms_per_step"] / d["ms_per_step"] < 1.1
 
 
 def test_bench_two_ranks_share_the_gpu():

@@ -60,6 +60,19 @@ def test_columns(path):
             assert_close(s.I_saved[k], d["I_saved"][k], PIN * 50, "order %d" % (k + 1))
 
 
+@pytest.mark.parametrize("path", golden("g3_spec_*.npz"), ids=lambda p: p.split("/")[-1][:-4])
+def test_first_order_yardstick_in_long_double(path):
+    """`first_order_extended` (the formulas of spec:113-292 with long-double intermediates on the same inputs: the yardstick for
+    the rounding noise of the reference's own arithmetic, see its docstring) against the reference's first order.  The golden
+    'mu0node' column has mu0 ON a node (the limit form of spec:126 applies); the others are far from any node."""
+    d, c = column_case(path)
+    col = oracle_column(O, c)
+    ext = O.first_order_extended(col)
+    assert ext.dtype == np.float64 and np.finfo(np.longdouble).nmant >= 63
+    assert_close(ext, d["I_saved"][0], 1e-10, "I1 in long double vs the reference")
+    assert np.max(np.abs(ext - d["I_saved"][0])) <= 2e-13 * np.max(np.abs(ext))
+
+
 def test_zone_table_reduces_to_the_three_zones():
     """The zone-table generalisation (SURVEY 8f-4) with the reference's three zones is the same arithmetic, bit for bit;
     two aerosol layers run, stay positive and converge (more than one slab is parity unpinned: the reference has one)."""

@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.join(ROOT, "sos-radiative-transfer_amd"))
 import numpy as np
 import torch
 
+os.environ.setdefault("SOSRT_GROUPS", "1")      # one column group as in bench.py's headline: every kernel alone on the GPU
+
 import bench
 from sosrt.solver import Solver
 
