@@ -722,11 +722,11 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
     std::vector<int> slab, plain, iup(B, 0), idn(B, 0);
     auto zone_end = [&](int b, int z) { return z + 1 < nz[b] ? zr0[b * kMaxZones + z + 1] - 1 : L - 1; };
     // column groups of the order loop: two contiguous halves for a large batch
-    // (auto: two groups while one field of the batch, B L D doubles, is between 128 and 512 MB -- measured, round 3, EVA / wildfire
-    // sweeps with one and two groups alternating on one box: 384 x (200, 128) 4.05 -> 3.74 ms, 512 x (200, 128) 5.03 -> 4.78,
+    // (auto: two groups while one field of the batch, B L D doubles, is between 128 and 512 MB.  An empirical rule -- round 3, EVA /
+    // wildfire sweeps with one and two groups alternating on one box: 384 x (200, 128) 4.05 -> 3.74 ms, 512 x (200, 128) 5.03 -> 4.78,
     // 1024 x (200, 128) 9.2 -> 8.85, 512 x (200, 256) 13.1 -> 12.65; 256 x (200, 128) and 512 x (200, 64) unchanged; 512 x (400, 256)
-    // 13.35 -> 14.2, 4096 x (200, 128) 32.8 -> 34.8, 4096 x (400, 256) 100 -> 106: the halves' source function and radiance stay in
-    // the 256-MB memory-side cache between the contraction and the transport only when they are that small)
+    // 13.35 -> 14.2, 4096 x (200, 128) 32.8 -> 34.8, 4096 x (400, 256) 100 -> 106.  The gain is the MFMA-bound contraction of one half
+    // running beside the HBM-bound transport of the other; the HBM bytes of a solve are the same either way: 17.6 vs 18.0 GB by PMC)
     int want = h->want_groups;
     if (want == 0) {
         const double field_mb = (double)B * L * h->D * sizeof(double) / (1024.0 * 1024.0);

@@ -51,6 +51,9 @@ if tr:
     out["k_transport"] = {"launches_per_solve": n}
     for key in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch"):
         out["k_transport"][key] = sum(x[key] * x["launches_per_solve"] for x in tr) / n
+# whole solve: every counted kernel (with two column groups the launches are twice as many and half as large: compare this line)
+out["hbm_bytes_per_solve"] = sum(v["hbm_bytes_per_launch"] * v["launches_per_solve"] for k, v in out.items() if k != "k_transport")
+out["column_groups"] = os.environ.get("SOSRT_GROUPS", "1")
 out["kernel_sources_sha"] = sha()
 out["aerosol"] = os.environ.get("AEROSOL", "eva")
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/run_once.py 512 %d "
