@@ -69,7 +69,7 @@ def test_bench_two_column_groups_at_the_headline_size():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["check"]["ok"] and d["two_groups"]["same_bits_as_headline"]
-    assert 0.7 < d["two_groups"]["ms_per_step"] / d["ms_per_step"] < 1.1
+    assert 0.6 < d["two_groups"]["ms_per_step"] / d["ms_per_step"] < 1.25       # (0.94 on a quiet box)
 
 
 def test_bench_two_ranks_share_the_gpu():
