@@ -974,7 +974,7 @@ int sosrt_transport(sosrt_t* h, int B, const double* tau, const double* Jn, doub
     launch_smallmu(h->stream, h->g, B, h->d_tau, h->d_Jn, h->d_InB, h->d_desc, nullptr);
     prof_end(h, SOSRT_K_SMALLMU);
     prof_begin(h, SOSRT_K_TRANSPORT);
-    const bool ring_like = h->transport_mode >= 2 && h->ring_ok;
+    const bool ring_like = h->transport_mode >= 2 && h->ring_ok && (h->max_nz <= kRingZones || transport_ring_fits(h->g, h->max_nz));
     const int nzcap = h->max_nz > kRingZones ? h->max_nz : kRingZones;
     if (h->transport_mode >= 1 && h->fast_ok && (h->max_nz <= kRingZones || ring_like)) {
         launch_attenuation(h->stream, h->g, B, h->d_tau, h->d_E, nullptr);
@@ -1057,10 +1057,10 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     h->need_small = true;
     const int small_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;       // never equals an order tag
     bool small_published = false;
-    // The ring / chunk-parallel kernels take columns of any zone count (round 3: the boundaries beyond the reference's two are read
-    // from the column's descriptor, in the chunks that contain one); the register-streaming kernel knows three zones, so a batch
-    // with more goes to the general kernel where that one would run (odd N, N > 256).
-    const bool ring_like = h->transport_mode >= 2 && h->ring_ok;
+    // The ring / chunk-parallel kernels take columns of any zone count (round 3: an instantiation that tests every boundary of the
+    // zone table, chosen when the batch holds such a column); the register-streaming kernel knows three zones, so a batch with more
+    // goes to the general kernel where that one would run (odd N, N > 256).
+    const bool ring_like = h->transport_mode >= 2 && h->ring_ok && (h->max_nz <= kRingZones || transport_ring_fits(h->g, h->max_nz));
     const bool fast = h->transport_mode >= 1 && h->fast_ok && (h->max_nz <= kRingZones || ring_like);
     const int nzcap = h->max_nz > kRingZones ? h->max_nz : kRingZones;
     const int ring_mode = (h->transport_mode >= 2 && h->ring_ok) ? 3 : 1;

@@ -129,6 +129,7 @@ struct TransportArgs {
 void launch_transport_fast(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a);
 // transport_ring.hip: same sweeps, rows streamed through an LDS ring by loader waves
 bool transport_ring_ok(const Grid& g);
+bool transport_ring_fits(const Grid& g, int nzcap);            // ... with the per-zone tables of up to nzcap zones
 void launch_transport_ring(hipStream_t s, dim3 grid, const TransportArgs& a, int slots);
 // transport_scan.hip: the chunks of a sweep dealt to several waves (chunk-local recurrence + carried values)
 bool transport_scan_ok(const Grid& g);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
     __shared__ int s_flag[3];                                  // [0] redo the upward sweep row by row, [1] IndexError, [2] some row is flagged in s_nf
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
-    const ZoneRows<MZ> zr(dg);                                     // zone boundaries: two in scalars, the others in the descriptor
+    const ZoneRows<MZ> zr(dg);                                     // zone boundaries in scalars (MZ: all of them, else the reference's two)
     const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
     const int surface = dg->surface;
     const double rho = dg->rho;
@@ -656,7 +656,7 @@ void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int 
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, g_ring_debug, ring_fixcap(a.g));                           \
     } while (0)
-    // (a batch with a column of more than three zones: the instantiation that reads the other boundaries from the descriptors)
+    // (a batch with a column of more than three zones: the instantiation that tests every boundary of the zone table, ZoneRows<true>)
 #define SOSRT_RING_LAUNCH(ACC_, SAVED_)                                                                        \
     do {                                                                                                       \
         if (a.nzcap > kRingZones) SOSRT_RING_LAUNCH_Z(ACC_, SAVED_, true);                                     \
@@ -683,6 +683,14 @@ bool transport_ring_ok(const Grid& g) {
     // (the finishing of flagged rows works in the ring once the sweeps are over: it must fit two slots of the smallest form)
     if (flagged_rows_work_doubles(g.L, g.N) * sizeof(double) > 2 * slot_bytes * 2 / 3) return false;
     return 2 * slot_bytes + ring_extra_doubles(g, (nwc + 4) * 64) * sizeof(double) <= kRingLdsBytes;
+}
+
+// the same with the per-zone tables of a batch whose columns have up to nzcap zones
+bool transport_ring_fits(const Grid& g, int nzcap) {
+    if (!transport_ring_ok(g)) return false;
+    const int nwc = (g.N + 63) / 64, pieces = g.N <= 128 ? 1 : 2;
+    const size_t slot_bytes = (size_t)3 * TC * 128 * pieces * sizeof(double);
+    return 2 * slot_bytes + ring_extra_doubles(g, (nwc + 4) * 64, nzcap < kRingZones ? kRingZones : nzcap) * sizeof(double) <= kRingLdsBytes;
 }
 
 // slots: ring depth wanted (2..6)

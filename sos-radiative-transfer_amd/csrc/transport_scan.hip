@@ -160,7 +160,7 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 
     const ColDesc* __restrict__ dg = a.desc + b;
     const int nz = dg->nz;
-    const ZoneRows<MZ> zr(dg);                                     // zone boundaries: two in scalars, the others in the descriptor
+    const ZoneRows<MZ> zr(dg);                                     // zone boundaries in scalars (MZ: all of them, else the reference's two)
     const int nfix0 = dg->nfix[0], nfix1 = dg->nfix[1], nfix2 = dg->nfix[2];
     const int surface = dg->surface;
     const double rho = dg->rho;
@@ -1020,7 +1020,7 @@ void launch_scan_t(hipStream_t s, dim3 grid, const TransportArgs& a) {
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
     } while (0)
 #define SOSRT_SCAN_LAUNCH_N(ACC_, SAVED_, NC_) SOSRT_SCAN_LAUNCH_Z(ACC_, SAVED_, NC_, false)
-    // (a batch with a column of more than three zones: the instantiation that reads the other boundaries from the descriptors)
+    // (a batch with a column of more than three zones: the instantiation that tests every boundary of the zone table, ZoneRows<true>)
 #define SOSRT_SCAN_LAUNCH(ACC_, SAVED_)                                                                        \
     do {                                                                                                       \
         if (a.nzcap > kRingZones) SOSRT_SCAN_LAUNCH_Z(ACC_, SAVED_, 0, true);                                  \

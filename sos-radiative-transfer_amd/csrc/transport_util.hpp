@@ -113,10 +113,10 @@ __device__ __forceinline__ double fix_acc(double c, double x, double acc) { retu
 // ---- the zone table as the sweeps look at it -------------------------------------------------------------------------------
 // Which rows end a zone that has another below it, which rows start a zone other than the first, which zone a row is in.  The
 // reference's three zones (spec:113-449) are two boundaries held in scalars -- the sweeps of a (clear, slab, clear) column
-// execute exactly what they did when the kernels knew nothing else --; the boundaries of a column with more aerosol layers
-// (up to kMaxZones zones) are read from its descriptor, in the chunks that contain one only.
-// (MZ: the kernel instantiation for batches that hold a column of more than three zones; without it the tests of the other
-// boundaries are not compiled at all)
+// execute exactly what they did when the kernels knew nothing else.  MZ is the instantiation for a batch that holds a column of
+// more aerosol layers (up to kMaxZones zones): the first rows of zones 3 .. 7 are scalars as well (-99 past the last
+// zone), every test is a few more scalar compares, and a three-zone column of such a batch gets the bits it has anywhere else.
+// Without MZ those compares are not compiled at all (as run-time branches they cost a lone column 1.5 us per order).
 template <bool MZ> struct ZoneRows {
     const ColDesc* dg;
     int nz, zend0, zend1, zbeg1, zbeg2;
