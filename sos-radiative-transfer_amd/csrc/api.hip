@@ -146,6 +146,8 @@ struct sosrt_handle {
     double* d_scan_scratch = nullptr;    // [max_batch][transport_scan_scratch_doubles()] exchange rows of the split form
     int* d_scan_sync = nullptr;          // [max_batch][2] {arrivals, flags}, zero between launches
     int gemm_tail_cols = 1 << 30;        // at or below this many live columns (and below the batch) tiles are laid over live columns (SOSRT_GEMM_TAIL)
+    double gemm_tail_frac = 0.6;         // ... and at or below this fraction of the group's columns (SOSRT_GEMM_TAIL_FRAC): above it the dense
+                                         // tiling, skipping the tiles of converged columns, is the faster one (contraction -3 % per step at 512 ... 4096 columns)
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
     bool fast_ok = false;
     double* d_ratio = nullptr;
@@ -434,6 +436,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_SCAN_COLS")) h->scan_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_SCAN_SPLIT")) h->scan_split = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
+    if (const char* ev = getenv("SOSRT_GEMM_TAIL_FRAC")) h->gemm_tail_frac = atof(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : (atoi(ev) == 1 ? 1 : 0);      // column groups of the order loop (0: auto)
     if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
@@ -1165,6 +1168,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             // (the tilings over the live columns whenever some column has converged -- and for a small batch from the start:
             // their 32-row tiles put a few columns on more CUs than the dense tiling's 64-row tiles; same bits either way)
             const int tail_cols = (h->contraction != SOSRT_CONTRACT_F32 && h->simple_zones && q.known <= h->gemm_tail_cols &&
+                                   (q.known <= h->gemm_tail_frac * q.nb || q.nb <= h->gemm_small_cols) &&
                                    (q.known < q.nb || q.nb <= h->gemm_small_cols)) ? q.known : 0;
             run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
