@@ -68,8 +68,12 @@ struct sosrt_handle {
     int ngroups = 1, want_groups = 0, split_min = 256;      // want_groups 0: by the size of the batch's field (set_columns)
     int split_at = -1;                   // SOSRT_GROUP_SPLIT: first column of the second group (default: the middle)
     int prio2 = 0;                       // SOSRT_GROUP_PRIO: the internal stream is created with the highest priority
-    int coresident_pad = 27008;         // SOSRT_GEMM_PAD_LDS: 27 656 static + this > 1/3 of 160 KiB
-    int coresident_slots = 2;           // SOSRT_GROUP_RING_SLOTS: ring depth of the transport when two groups share the CUs
+    // Round 2 capped the contraction at two workgroups per CU with LDS padding (27 008 bytes: 27 656 static + this > 1/3 of 160 KiB)
+    // and ran the ring two slots deep, so that a transport workgroup of the other group fits beside them on every CU.  With round 3's
+    // kernels the uncapped contraction and a three-slot ring are faster under two groups (alternating runs: 512 columns 4.81 -> 4.75 ms,
+    // 1024 columns 8.45 -> 8.15, 384 columns unchanged): the groups share the GPU CU by CU rather than inside a CU.
+    int coresident_pad = 0;             // SOSRT_GEMM_PAD_LDS
+    int coresident_slots = 3;           // SOSRT_GROUP_RING_SLOTS: ring depth of the transport under two groups
     double stagger = 1.0;                // a group starts when the previous one is down to this fraction of live columns (SOSRT_STAGGER; 1: together)
     int gb[kMaxGroups + 1] = {0, 0, 0};                    // column range of group g: [gb[g], gb[g+1])
     int main_off[kMaxGroups + 1] = {0, 0, 0};              // its plain rows in d_mainrows

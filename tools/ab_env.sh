@@ -8,4 +8,4 @@ run() {  # columns layers angles aerosol steps
     env $cfg timeout -k 10 200 python bench.py --groups $G --columns $1 --layers $2 --angles $3 --aerosol $4 --steps $5 --warmup 2 --no-extras --no-cpu-baseline --pipelined 0 --check-columns 1 >> $out 2>&1 || return 1
   done; done
 }
-run 512 200 128 eva 20 && run 256 200 128 eva 20 && run 1024 200 128 eva 10 && run 4096 200 128 eva 4 && run 512 200 256 eva 10 && run 4096 400 256 wildfire 3 && run 512 200 64 eva 20
+if [ -n "$SHAPES" ]; then eval "$SHAPES"; else run 512 200 128 eva 20 && run 256 200 128 eva 20 && run 1024 200 128 eva 10 && run 4096 200 128 eva 4 && run 512 200 256 eva 10 && run 4096 400 256 wildfire 3 && run 512 200 64 eva 20; fi
