@@ -26,7 +26,7 @@ timed region, `--no-extras` skips them): `extras.c2` / `extras.c3` = one EVA col
 configs[1], [2]: single-column latency), `extras.c5` = the 4096-column wildfire sweep at L = 400, N = 256 (configs[4]),
 each with its own check against the oracle.  `--groups 1` (default) runs the headline's order loop as one column group on one
 stream, so that every kernel is timed alone on the GPU (the roofline objects are per kernel); the library by itself takes two
-groups on two streams for a batch of this size, which is faster: `two_groups` holds that measurement (same sweep, same bits).
+groups on two streams for a batch of more than 256 columns, which is faster: `two_groups` holds that measurement (same sweep, same bits).
 """
 import argparse
 import json
@@ -547,8 +547,7 @@ def main():
                 l2.solve()
             torch.cuda.synchronize(dev)
             dt2 = (time.perf_counter() - t20) / tsteps
-            two = {"order_loop": "SOSRT_GROUPS unset: the library's choice (two column groups on two streams while one field of the "
-                                 "batch is between 128 and 512 MB)", "steps": tsteps, "ms_per_step": dt2 * 1e3,
+            two = {"order_loop": "SOSRT_GROUPS unset: the library's choice (two column groups on two streams for a batch of more than 256 columns)", "steps": tsteps, "ms_per_step": dt2 * 1e3,
                    "value": B / dt2, "unit": "columns/s",
                    "same_bits_as_headline": bool(torch.equal(l2.I, lanes[0].I) and torch.equal(l2.n, lanes[0].n))}
         finally:

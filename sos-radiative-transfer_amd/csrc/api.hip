@@ -65,7 +65,7 @@ struct sosrt_handle {
     static constexpr int kMaxGroups = 2;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int ngroups = 1, want_groups = 0, split_min = 256;      // want_groups 0: by the size of the batch's field (set_columns)
+    int ngroups = 1, want_groups = 0, split_min = 256;      // want_groups 0: two groups above split_min columns (set_columns)
     int split_at = -1;                   // SOSRT_GROUP_SPLIT: first column of the second group (default: the middle)
     int prio2 = 0;                       // SOSRT_GROUP_PRIO: the internal stream is created with the highest priority
     // Round 2 capped the contraction at two workgroups per CU with LDS padding (27 008 bytes: 27 656 static + this > 1/3 of 160 KiB)
@@ -729,16 +729,14 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
     std::vector<int> slab, plain, iup(B, 0), idn(B, 0);
     auto zone_end = [&](int b, int z) { return z + 1 < nz[b] ? zr0[b * kMaxZones + z + 1] - 1 : L - 1; };
     // column groups of the order loop: two contiguous halves for a large batch
-    // (auto: two groups while one field of the batch, B L D doubles, is between 128 and 512 MB.  An empirical rule -- round 3, EVA /
-    // wildfire sweeps with one and two groups alternating on one box: 384 x (200, 128) 4.05 -> 3.74 ms, 512 x (200, 128) 5.03 -> 4.78,
-    // 1024 x (200, 128) 9.2 -> 8.85, 512 x (200, 256) 13.1 -> 12.65; 256 x (200, 128) and 512 x (200, 64) unchanged; 512 x (400, 256)
-    // 13.35 -> 14.2, 4096 x (200, 128) 32.8 -> 34.8, 4096 x (400, 256) 100 -> 106.  The gain is the MFMA-bound contraction of one half
-    // running beside the HBM-bound transport of the other; the HBM bytes of a solve are the same either way: 17.6 vs 18.0 GB by PMC)
+    // (auto: two groups for a batch of more than SPLIT_MIN = 256 columns.  Round 3, EVA / wildfire sweeps with one and two groups
+    // alternating on one box: 288 x (200, 128) 3.65 -> 3.33 ms, 320 x 3.89 -> 3.50, 512 x 5.03 -> 4.75, 1024 x 9.2 -> 8.15,
+    // 2048 x 16.6 -> 15.5, 4096 x 32.4 -> 30.3; 512 x (200, 64) 3.02 -> 2.94, 1024 x (200, 64) 5.10 -> 4.69; 512 x (200, 256)
+    // 13.1 -> 12.65, 512 x (400, 256) 13.5 -> 12.8, 4096 x (400, 256) 106 -> 103.7; 256 x (200, 128) unchanged.  The gain is the
+    // MFMA-bound contraction of one half running beside the HBM-bound transport of the other; the HBM bytes of a solve are the same
+    // either way: 17.6 vs 18.0 GB by PMC)
     int want = h->want_groups;
-    if (want == 0) {
-        const double field_mb = (double)B * L * h->D * sizeof(double) / (1024.0 * 1024.0);
-        want = (field_mb > 128.0 && field_mb <= 512.0) ? 2 : 1;
-    }
+    if (want == 0) want = B > h->split_min ? 2 : 1;
     h->ngroups = (want >= 2 && B >= h->split_min && B >= 2) ? 2 : 1;
     h->gb[0] = 0; h->gb[1] = h->ngroups == 2 ? ((h->split_at > 0 && h->split_at < B) ? h->split_at : B / 2) : B; h->gb[2] = B;
     for (int k = 0; k <= sosrt_handle::kMaxGroups; ++k) { h->main_off[k] = 0; h->slab_off[k] = 0; }
