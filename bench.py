@@ -512,27 +512,11 @@ def main():
             check["gather_places_columns"] = bool(torch.equal(gI[sel], mineI))
             check["ok"] = bool(check["ok"] and check["gather_places_columns"])
 
-    # Beside the headline (one step at a time, one stream: every kernel timing above is of a launch that
-    # has the GPU to itself): the same steps with `--pipelined` of them in flight on separate streams and
-    # handles.  The tail of one sweep's order loop then overlaps the dense launches of the next.
-    pipe = None
-    if a.pipelined > 1 and len(lanes) == 1 and world == 1:
-        while len(lanes) < a.pipelined:
-            lanes.append(Lane(w, dev, local_rank, a.max_orders, lanes[0].shared()))
-            execs.append(ThreadPoolExecutor(max_workers=1))
-        psteps = max(a.steps, 2 * a.pipelined)
-        run_steps(a.pipelined)
-        sync_all()
-        tp0 = time.perf_counter()
-        run_steps(psteps)
-        sync_all()
-        dtp = time.perf_counter() - tp0
-        pipe = {"steps_in_flight": a.pipelined, "steps": psteps, "value": B * psteps / dtp, "unit": "columns/s",
-                "ms_per_step": dtp / psteps * 1e3}
-
     # Beside the headline too: the same sweep with the order loop the library chooses by itself for a batch of this size -- two
     # column groups on two streams -- one step at a time; the field must have the headline's bits.
     two = None
+    # (measured before the `pipelined` lanes exist: HIP maps streams onto a few hardware queues, and with eight streams alive the
+    # two streams of this handle can land on one queue and serialise)
     if world == 1 and a.groups == "1" and not a.no_extras:
         os.environ.pop("SOSRT_GROUPS", None)
         l2 = Lane(w, dev, local_rank, a.max_orders, lanes[0].shared())
@@ -552,6 +536,24 @@ def main():
                    "same_bits_as_headline": bool(torch.equal(l2.I, lanes[0].I) and torch.equal(l2.n, lanes[0].n))}
         finally:
             l2.close()
+
+    # Beside the headline (one step at a time, one stream: every kernel timing above is of a launch that
+    # has the GPU to itself): the same steps with `--pipelined` of them in flight on separate streams and
+    # handles.  The tail of one sweep's order loop then overlaps the dense launches of the next.
+    pipe = None
+    if a.pipelined > 1 and len(lanes) == 1 and world == 1:
+        while len(lanes) < a.pipelined:
+            lanes.append(Lane(w, dev, local_rank, a.max_orders, lanes[0].shared()))
+            execs.append(ThreadPoolExecutor(max_workers=1))
+        psteps = max(a.steps, 2 * a.pipelined)
+        run_steps(a.pipelined)
+        sync_all()
+        tp0 = time.perf_counter()
+        run_steps(psteps)
+        sync_all()
+        dtp = time.perf_counter() - tp0
+        pipe = {"steps_in_flight": a.pipelined, "steps": psteps, "value": B * psteps / dtp, "unit": "columns/s",
+                "ms_per_step": dtp / psteps * 1e3}
 
     cpu_t = dev if on_gpu else "cpu"
     t = torch.tensor([dt], dtype=torch.float64, device=cpu_t)

@@ -465,13 +465,8 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             // where a caller without an explicit stream -- torch's default stream is that one -- fills and reads its buffers
             HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault));
             h->stream = h->own_stream;
-            if (h->prio2) {
-                int least = 0, greatest = 0;
-                HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, h->prio2 > 0 ? greatest : least));
-            } else {
-                HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-            }
+            // (the second group's stream is created when a batch first takes two groups: HIP maps streams onto a few hardware
+            // queues, and a handle that never splits should not take one from the caller's other streams)
             HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             const size_t mb = max_batch, fe = field_elems(h);
@@ -738,6 +733,16 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
     int want = h->want_groups;
     if (want == 0) want = B > h->split_min ? 2 : 1;
     h->ngroups = (want >= 2 && B >= h->split_min && B >= 2) ? 2 : 1;
+    if (h->ngroups > 1 && !h->stream2) {
+        HIPCHK(hipSetDevice(h->device));
+        if (h->prio2) {
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, h->prio2 > 0 ? greatest : least));
+        } else {
+            HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        }
+    }
     h->gb[0] = 0; h->gb[1] = h->ngroups == 2 ? ((h->split_at > 0 && h->split_at < B) ? h->split_at : B / 2) : B; h->gb[2] = B;
     for (int k = 0; k <= sosrt_handle::kMaxGroups; ++k) { h->main_off[k] = 0; h->slab_off[k] = 0; }
     h->max_nz = 1;
@@ -1656,7 +1661,7 @@ int sosrt_profile_enable(sosrt_t* h, int on) {
 int sosrt_profile_reset(sosrt_t* h) {
     if (int e = need_gpu(h)) return e;
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream2));
+    if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
     for (Prof& p : h->prof) { p.used = 0; p.nint = 0; p.adjacent = -1; p.open = -1; }
     return 0;
 }
@@ -1664,7 +1669,7 @@ int sosrt_profile_reset(sosrt_t* h) {
 int sosrt_profile_get(sosrt_t* h, int kernel, double* total_ms, long long* launches, double* work) {
     if (int e = need_gpu(h)) return e;
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream2));
+    if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
     double tot = 0;
     long long cnt = 0;
     for (Prof& p : h->prof)
