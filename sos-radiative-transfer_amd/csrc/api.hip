@@ -1226,10 +1226,8 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     prof_break(h);
-    launch_finalize(s, B, make_conv(h, tol), h->max_orders);
+    launch_finalize(s, B, make_conv(h, tol), h->max_orders, d_n_orders_out, d_status_out);
     HIPCHK(hipGetLastError());
-    if (d_n_orders_out) HIPCHK(hipMemcpyAsync(d_n_orders_out, h->d_norders, B * sizeof(int), hipMemcpyDeviceToDevice, s));
-    if (d_status_out) HIPCHK(hipMemcpyAsync(d_status_out, h->d_status, B * sizeof(int), hipMemcpyDeviceToDevice, s));
     h->last_max_orders = n_max;
     h->last_sum_orders = -1;
     return 0;

@@ -1179,12 +1179,17 @@ void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, co
 }
 
 // columns still iterating when the order budget is exhausted
-__global__ void k_finalize(int B, Conv cv, int max_orders) {
+// (and the caller's copies of the order counts and the status words, instead of two device-to-device copies behind it)
+__global__ void k_finalize(int B, Conv cv, int max_orders, int* __restrict__ n_out, int* __restrict__ status_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && cv.active[b]) cv.status[b] = SOSRT_COL_MAXORDERS;
+    if (b >= B) return;
+    int st = cv.status[b];
+    if (cv.active[b]) { st = SOSRT_COL_MAXORDERS; cv.status[b] = st; }
+    if (n_out) n_out[b] = cv.norders[b];
+    if (status_out) status_out[b] = st;
 }
-void launch_finalize(hipStream_t s, int B, Conv cv, int max_orders) {
-    hipLaunchKernelGGL(k_finalize, dim3((B + 127) / 128), dim3(128), 0, s, B, cv, max_orders);
+void launch_finalize(hipStream_t s, int B, Conv cv, int max_orders, int* n_out, int* status_out) {
+    hipLaunchKernelGGL(k_finalize, dim3((B + 127) / 128), dim3(128), 0, s, B, cv, max_orders, n_out, status_out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -254,7 +254,7 @@ void launch_phase_matrix(hipStream_t s, const Grid& g, const double* w, int kind
 void launch_limit_rows(hipStream_t s, const Grid& g, int R, int table, const double* rows, double* out);
 void launch_asymptotic(hipStream_t s, int R, int stride, const int* len, const double* J, const double* tau,
                        const double* tau_t, const double* mu, double* out);
-void launch_finalize(hipStream_t s, int B, Conv cv, int max_orders);
+void launch_finalize(hipStream_t s, int B, Conv cv, int max_orders, int* n_out = nullptr, int* status_out = nullptr);
 void launch_bench(hipStream_t s, int which, double* a, double* b, size_t n, int iters);
 
 }  // namespace sosrt
