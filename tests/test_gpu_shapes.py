@@ -321,8 +321,8 @@ def test_sharded_solve_equals_single_rank_bit_for_bit():
 
 def test_two_column_groups_on_two_streams_are_bit_identical(monkeypatch):
     """SOSRT_GROUPS=2: the order loop runs per half of the batch, the second half on an internal stream, contraction and
-    transport of the two halves side by side on the CUs (capped contraction occupancy, two-slot ring).  Same bits as
-    the single-group loop -- and the tilings differ, so this is also a batch-invariance check."""
+    transport of the two halves side by side on the CUs.  Same bits as the single-group loop -- and the tilings differ, so this
+    is also a batch-invariance check."""
     from sosrt import main as M
     rng = np.random.default_rng(11)
     B = 600
@@ -344,6 +344,38 @@ def test_two_column_groups_on_two_streams_are_bit_identical(monkeypatch):
     assert (a.status == 0).all()
     assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
     assert np.array_equal(a.I, b.I)                         # bit for bit
+
+
+def test_default_grouping_of_a_large_batch_keeps_the_bits(monkeypatch):
+    """The library's own choice (SOSRT_GROUPS unset: two column groups above 256 columns) against one group, on an odd batch size
+    (groups of 150 and 151 columns) of two-layer columns -- zone tables of five zones, the zone-table instantiation of the ring /
+    chunk-parallel kernels, a surface that reflects -- and every column against a batch of its own kind solved alone."""
+    from sosrt import main as M
+    from sosrt.main import SOS_Aer_layers
+    rng = np.random.default_rng(31)
+    B = 301
+    mu0 = rng.uniform(0.2, 1.0, B)
+    rho = rng.uniform(0.0, 0.8, B)
+    slabs = [(60, 50, 0.12, 0.90), (25, 17, 0.20, 0.97)]
+    kw = dict(tauStar_atm=0.124, nb_layers=48, nb_angles=64, aer_phase_fun="hg", g_aer=0.7, max_orders=200)
+    out = []
+    for groups in ("1", None):
+        if groups is None:
+            monkeypatch.delenv("SOSRT_GROUPS", raising=False)
+        else:
+            monkeypatch.setenv("SOSRT_GROUPS", groups)
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+        out.append(SOS_Aer_layers(mu0, rho, slabs, **kw))
+    sub = SOS_Aer_layers(mu0[148:153], rho[148:153], slabs, **kw)      # five columns across the cut, alone (one group)
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    a, b = out
+    assert (a.status == 0).all()
+    assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status) and np.array_equal(a.I, b.I)
+    assert np.array_equal(sub.n, b.n[148:153]) and np.array_equal(sub.I, b.I[148:153])
 
 
 def test_transport_kernel_follows_the_live_count_with_the_same_bits(monkeypatch):
