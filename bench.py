@@ -24,7 +24,10 @@ No collective runs inside the order loop.
 Prints ONE JSON line on rank 0 (see the contract in the task description).  Beside the headline (N = 1 only, outside its
 timed region, `--no-extras` skips them): `extras.c2` / `extras.c3` = one EVA column at N_mu = 128 / 256 (BASELINE
 configs[1], [2]: single-column latency), `extras.c5` = the 4096-column wildfire sweep at L = 400, N = 256 (configs[4]),
-each with its own check against the oracle.  `--groups 1` (default) runs the headline's order loop as one column group on one
+each with its own check against the oracle; `extras.c4_shard` = the 64 columns rank 0 gets when the C4 sweep is dealt to 8 GPUs
+(BASELINE configs[3]: what bounds the 8-GPU strong-scaling number, measurable on one GPU); `extras.c4_hg` = the headline sweep
+with the HG(0.7) stand-in of rounds 1-2 (continuity).  With several GPUs the line also carries `strong`: the ONE-sweep-over-the-node
+measurement of configs[3] (fields gathered through the C ABI under RCCL) beside the weak-scaling headline.  `--groups 1` (default) runs the headline's order loop as one column group on one
 stream, so that every kernel is timed alone on the GPU (the roofline objects are per kernel); the library by itself takes two
 groups on two streams for a batch of more than 256 columns, which is faster: `two_groups` holds that measurement (same sweep, same bits).
 """
@@ -41,7 +44,7 @@ import numpy as np
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix, vendor datasheet; the microarch guide lists no f64 row
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
 
 # what the sweeps vary around (README.md:95-111): slab altitudes, range of tau*_aer, aerosol single-scattering albedo
 SCENARIOS = {
@@ -56,7 +59,8 @@ def kernel_sources_sha():
     """Digest of the kernel sources the PMC traffic figures belong to."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("jn_gemm.hip", "transport_ring.hip", "transport_scan.hip", "kernels.hpp", "transport_util.hpp"):
+    for name in ("jn_gemm.hip", "jn_gemm_tile.hpp", "transport_ring.hip", "transport_scan.hip", "transport_scan_body.hpp", "order_loop.hip",
+                 "kernels.hpp", "transport_util.hpp"):
         with open(os.path.join(ROOT, "sos-radiative-transfer_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -253,11 +257,11 @@ class Lane:
         self.s.close()
 
 
-def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, max_orders=256):
+def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, max_orders=256, sweep=None):
     """One more configuration of BASELINE.json beside the headline, outside its timed region: `steps` solves one at a time on
-    one stream, wall time, its own check."""
+    one stream, wall time, its own check.  `sweep`: a prepared sweep (build_sweep / take) instead of n_columns."""
     import torch
-    w = build_sweep(n_columns, L, N, 0, 1, aerosol=aerosol) if n_columns > 1 else None
+    w = sweep if sweep is not None else (build_sweep(n_columns, L, N, 0, 1, aerosol=aerosol) if n_columns > 1 else None)
     if w is None:          # one column at the scenario's own values (README.md:95-111)
         from sosrt import inputs
         sc = SCENARIOS[aerosol]
@@ -281,8 +285,11 @@ def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, 
         orders = int((n - 1).sum())
         out = {"workload": "%d column%s, L=%d, N=%d, Rayleigh + %s" % (w["B"], "" if w["B"] == 1 else "s", L, N, SCENARIOS[aerosol]["label"]),
                "ms_per_solve": dt * 1e3, "columns_per_s": w["B"] / dt, "orders": orders, "max_order": int(n.max()),
-               "us_per_order_launch_group": dt * 1e6 / max(int(n.max()) - 1, 1), "not_converged": int((ln.st.cpu().numpy() != 0).sum()),
+               "us_per_order": dt * 1e6 / max(int(n.max()) - 1, 1), "not_converged": int((ln.st.cpu().numpy() != 0).sum()),
                "steps": steps}
+        ol = ln.s.order_loop_stats(True)
+        out["order_loop_launches"] = {"launches": ol[0], "refused": ol[1], "column_orders": int(ol[2]),
+                                      "note": "orders of the last solve that ran inside order-loop launches (csrc/order_loop.hip)"}
         # single-GPU roofline of SURVEY 8(d) for this shape: max(t_flop, t_byte), both flop conventions
         D = 2 * N
         t_flop = 2.0 * L * D * D * orders / (FP64_MFMA_PEAK_TFLOPS * 1e12)
@@ -292,6 +299,78 @@ def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, 
         if check_cols:
             out["check"] = dict(ln.check(O, check_cols), columns=[int(b) for b in check_cols])
         return out
+    finally:
+        ln.close()
+
+
+def measure_strong(a, dev, local_rank, rank, world, on_gpu):
+    """BASELINE configs[3] beside a weak-scaling headline: ONE sweep of --columns columns dealt to the ranks, every rank solves its
+    shard, the fields are gathered to rank 0 once per step (no collective in the order loop).  Timed like the headline: barrier +
+    synchronize on both sides of exactly --steps steps, max over ranks.  Returns the object on rank 0 (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    from sosrt import dist as sdist
+    w1 = build_sweep(a.columns, a.layers, a.angles, 0, 1, vary_albedo=False, aerosol=a.aerosol)
+    plan = sdist.GatherPlan(w1["B"], world, sdist.expected_orders(w1["tau_atm"] + w1["taer"], w1["rho"]))
+    mine = plan.mine(rank)
+    if len(mine) == 0:
+        return {"status": "skipped: fewer columns than ranks"} if rank == 0 else None
+    ws = take(w1, mine)
+    via = "abi" if on_gpu else "torch"
+    os.environ.pop("SOSRT_GROUPS", None)                      # the library's own order loop for a shard of this size
+    ln = Lane(ws, dev, local_rank, a.max_orders)
+    os.environ["SOSRT_GROUPS"] = a.groups if a.groups != "auto" else os.environ.get("SOSRT_GROUPS", "")
+    if os.environ["SOSRT_GROUPS"] == "":
+        os.environ.pop("SOSRT_GROUPS")
+    got = {}
+    try:
+        if via == "abi":
+            sdist._comm_for(ln.s, None, 0)
+
+        def step():
+            ln.solve()
+            if via == "abi":
+                with torch.cuda.stream(ln.stream):
+                    got["I"] = sdist.gather_rows(ln.I, plan, dst=0, key="sI", via="abi", solver=ln.s)
+                    got["n"] = sdist.gather_rows(ln.n.to(torch.float64)[:, None].contiguous(), plan, dst=0, key="sn", via="abi", solver=ln.s)
+            else:
+                ln.stream.synchronize()
+                got["I"] = sdist.gather_rows(ln.I if on_gpu else ln.I.cpu(), plan, dst=0, key="sI")
+                got["n"] = sdist.gather_rows(ln.n if on_gpu else ln.n.cpu(), plan, dst=0, key="sn")
+
+        def sync():
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(max(1, a.warmup)):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sync()
+        dts = time.perf_counter() - t0
+        cpu_t = dev if on_gpu else "cpu"
+        t = torch.tensor([dts], dtype=torch.float64, device=cpu_t)
+        pr = torch.zeros(world, 2, dtype=torch.float64, device=cpu_t)
+        pr[rank, 0] = len(mine)
+        pr[rank, 1] = float((ln.n.cpu().numpy() - 1).sum())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pr)
+        if rank != 0:
+            return None
+        dts = float(t.item())
+        pr = pr.cpu().numpy()
+        gI = plan.restore(got["I"])
+        sel = torch.as_tensor(np.asarray(mine)[[0, len(mine) - 1]], device=gI.device)
+        placed = bool(torch.equal(gI[sel], torch.stack([ln.I[0], ln.I[len(mine) - 1]]).to(gI.device)))
+        return {"metric": "SOS columns/sec to 1e-4 convergence, ONE sweep over the node (BASELINE configs[3])", "scaling": "strong",
+                "value": w1["B"] * a.steps / dts, "unit": "columns/s", "n_gpus": world, "steps": a.steps, "ms_per_step": dts / a.steps * 1e3,
+                "columns": int(w1["B"]), "columns_per_gpu": [int(x) for x in pr[:, 0]], "orders_per_step_per_rank": [int(x) for x in pr[:, 1]],
+                "gather": "whole fields to rank 0 once per step, " + ("the C ABI's sosrt_gather (ncclSend / ncclRecv over RCCL)" if via == "abi"
+                                                                       else "torch.distributed point-to-point (gloo rehearsal)"),
+                "gather_places_columns": placed}
     finally:
         ln.close()
 
@@ -480,13 +559,18 @@ def main():
     n_host = lanes[0].n.cpu().numpy()
     st_host = lanes[0].st.cpu().numpy()
     orders_per_step = int((n_host - 1).sum())
-    gemm_ms = tr_ms = fo_ms = 0.0
-    gemm_launches = tr_launches = 0
+    gemm_ms = tr_ms = fo_ms = ol_ms = 0.0
+    gemm_launches = tr_launches = ol_launches = 0
     for ln in lanes:
         ms, cnt = ln.s.profile_get(_lib.K_GEMM); gemm_ms += ms; gemm_launches += cnt
         ms, cnt = ln.s.profile_get(_lib.K_TRANSPORT); tr_ms += ms; tr_launches += cnt
+        ms, cnt = ln.s.profile_get(_lib.K_ORDER_LOOP); ol_ms += ms; ol_launches += cnt
         fo_ms += ln.s.profile_get(_lib.K_FIRST)[0]
         ln.s.profile_enable(False)
+    # (column, order) pairs of a step that ran inside order-loop launches (the last orders of the last live columns: one launch
+    # holds the transport and the contraction of all of them) -- the same in every step
+    ol_stats = lanes[0].s.order_loop_stats(True)
+    ol_orders_per_step = int(ol_stats[2])
 
     # Outside the timed region: sampled columns of the field the last timed step left on the device against the oracle.
     # Rank 0, its own columns.
@@ -555,6 +639,13 @@ def main():
         pipe = {"steps_in_flight": a.pipelined, "steps": psteps, "value": B * psteps / dtp, "unit": "columns/s",
                 "ms_per_step": dtp / psteps * 1e3}
 
+    # Several GPUs, weak-scaling headline: the same command also measures BASELINE configs[3] -- ONE sweep over the node, dealt to
+    # the ranks by expected work (sosrt.dist.GatherPlan), the whole fields gathered to rank 0 once per step (through the C ABI's
+    # sosrt_gather under RCCL; torch.distributed point-to-point in the gloo rehearsal) -- so that one driver run yields both curves.
+    strong_obj = None
+    if world > 1 and not strong:
+        strong_obj = measure_strong(a, dev, local_rank, rank, world, on_gpu)
+
     cpu_t = dev if on_gpu else "cpu"
     t = torch.tensor([dt], dtype=torch.float64, device=cpu_t)
     per_rank = torch.zeros(world, 2, dtype=torch.float64, device=cpu_t)
@@ -575,7 +666,9 @@ def main():
         # flip-symmetric and the library runs the two N x N products (sosrt.h, sosrt_set_contraction) -- `achieved` counts
         # those, the rate in units of the full product is reported beside it.
         asym, uses_sym = lanes[0].s.phase_asymmetry()
-        KO = orders_per_step * a.steps                            # column.orders in the timed region (this rank)
+        KO_all = orders_per_step * a.steps                        # column.orders in the timed region (this rank)
+        KO_ol = ol_orders_per_step * a.steps                      # ... of which inside order-loop launches
+        KO = KO_all - KO_ol                                       # ... and as two launches per order: the work of the two kernels below
         full_flops = 2.0 * L * D * D * KO
         flops = full_flops / 2 if uses_sym else full_flops
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -598,8 +691,9 @@ def main():
                        "max_order": int(n_host.max()),
                        "not_converged": int((st_host != 0).sum()), "inflight_solves": max(1, a.inflight),
                        "p0": "built on the device (sosrt_phase_p0_dev), outside the timed region",
+                       "library_default": bool(a.groups == "auto" or B <= 256),
                        "order_loop": {"1": "one column group, one stream (SOSRT_GROUPS=1): no kernel runs beside another; the library "
-                                           "alone takes two groups at this size: `two_groups`",
+                                           "alone takes two groups at this size: `two_groups` is what a default library call executes",
                                       "2": "two column groups on two streams (SOSRT_GROUPS=2)",
                                       "auto": "the library's choice (SOSRT_GROUPS unset)"}[a.groups],
                        "gather": ({"digest": "digest (TOA / surface rows, order counts) to rank 0 once per step, torch.distributed gather",
@@ -610,7 +704,7 @@ def main():
                                       ("columns sharded x%d, gather only" % world)},
             "roofline": None, "roofline_other": None,
             "kernel_ms_per_step": {"k_jn_gemm": gemm_ms / a.steps, "k_transport": tr_ms / a.steps,
-                                   "k_first_order": fo_ms / a.steps},
+                                   "k_first_order": fo_ms / a.steps, "k_order_loop": ol_ms / a.steps},
         }
         if check is not None:
             out["check"] = check
@@ -618,7 +712,7 @@ def main():
                   "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                   "avg_launch_ms": gemm_ms / max(gemm_launches, 1), "launches": gemm_launches,
                   "total_ms_per_step": gemm_ms / a.steps,
-                  "work_per_launch": flops / max(gemm_launches, 1), "work_unit": "flop",
+                  "work_per_launch": flops / max(gemm_launches, 1), "work_unit": "flop", "column_orders_per_step": KO // max(a.steps, 1),
                   "flops_per_column_order": flops / max(KO, 1),
                   "form": ("flip-symmetric: two N x N products per row, L D^2 flops" if uses_sym else "full 2N x 2N product, 2 L D^2 flops"),
                   "matrix_asymmetry": asym,
@@ -626,7 +720,22 @@ def main():
         r_tr = {"bound": "hbm", "kernel": "k_transport_ring + k_transport_scan", "achieved": tr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": tr_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": tr_ms / max(tr_launches, 1),
                 "launches": tr_launches, "total_ms_per_step": tr_ms / a.steps,
-                "work_per_launch": tr_bytes / max(tr_launches, 1), "work_unit": "bytes (32 L D per column.order: read Jn, I; write In, I)"}
+                "work_per_launch": tr_bytes / max(tr_launches, 1), "work_unit": "bytes (32 L D per column.order: read Jn, I; write In, I)",
+                "column_orders_per_step": KO // max(a.steps, 1)}
+        # The order-loop launches: the last orders of the last live columns, transport and contraction of all of them in one
+        # launch (csrc/order_loop.hip).  Latency-bound by construction (a few columns on 256 CUs): priced like the transport, on
+        # the 32 L D bytes per column.order it moves, with the flops of its contraction role beside that.
+        ol_bytes = 32.0 * L * D * KO_ol
+        ol_flops = (L * D * D if uses_sym else 2.0 * L * D * D) * KO_ol
+        ol_gbs = ol_bytes / (ol_ms * 1e-3) / 1e9 if ol_ms > 0 else 0.0
+        r_ol = {"bound": "hbm", "kernel": "k_order_loop (transport + contraction roles of one launch)", "achieved": ol_gbs, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ol_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ol_ms / max(ol_launches, 1),
+                "launches": ol_launches, "total_ms_per_step": ol_ms / a.steps, "work_per_launch": ol_bytes / max(ol_launches, 1),
+                "work_unit": "bytes (32 L D per column.order)", "column_orders_per_step": ol_orders_per_step,
+                "orders_per_launch_longest_column": None,
+                "contraction_tflops": ol_flops / (ol_ms * 1e-3) / 1e12 if ol_ms > 0 else 0.0,
+                "refused_launches": int(ol_stats[1]),
+                "note": "latency-bound: the columns' serial chains, not the bytes"}
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of the same workload (the counters cannot be
         # read from inside this process).  The committed file names the source revision of the kernels it was
         # measured on; it is used only while those sources are unchanged, otherwise traffic stays null.
@@ -641,8 +750,11 @@ def main():
                 r_tr["frac_on_pmc_traffic"] = r_tr["traffic"] / (r_tr["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         except (OSError, KeyError, ValueError):
             pass
-        # the roofline object is the kernel with the larger share of the timed region
-        out["roofline"], out["roofline_other"] = (r_gemm, r_tr) if gemm_ms >= tr_ms else (r_tr, r_gemm)
+        # the roofline object is the kernel with the largest share of the timed region
+        ranked = sorted([(gemm_ms, 0, r_gemm), (tr_ms, 1, r_tr), (ol_ms, 2, r_ol)], key=lambda x: (-x[0], x[1]))
+        out["roofline"], out["roofline_other"] = ranked[0][2], ranked[1][2]
+        if ol_launches:
+            out["roofline_order_loop"] = r_ol
         # SURVEY 8(d), column level: the step against max(t_flop, t_byte) of one GPU's share.  t_flop in both conventions
         # (2 L D^2 per column.order as 8d writes it / L D^2 as the symmetric form executes); t_byte = the compulsory
         # 8 L D (4 K + 2) with Jn fused (+ 16 L D K while Jn round-trips HBM, as it does here).
@@ -666,15 +778,37 @@ def main():
                 ln.close()
             lanes.clear()
             torch.cuda.empty_cache()
-            os.environ.pop("SOSRT_GROUPS", None)          # (one column, or a 6.7-GB field: one group either way)
+            os.environ.pop("SOSRT_GROUPS", None)          # (the library's own order loop: one group for one column and for the 64-column shard, two for the 4096 columns of C5)
             ex = {}
             try:
                 ex["c2"] = extra_case(O, dev, local_rank, 1, 200, 128, "eva", 20, [0])
                 ex["c3"] = extra_case(O, dev, local_rank, 1, 200, 256, "eva", 20, [0])
                 ex["c5"] = extra_case(O, dev, local_rank, 4096, 400, 256, "wildfire", 2, [16 * 16 * 5 + 16 * 9 + 4])
+                # BASELINE configs[3] on one GPU: the shard rank 0 gets when the C4 sweep is dealt to 8 ranks (sosrt.dist.GatherPlan:
+                # sorted by expected orders, dealt in a snake), solved like the other extras.  512 columns / its time is the most
+                # an 8-GPU strong-scaling run of that sweep can reach before its gather.
+                w4 = build_sweep(512, 200, 128, 0, 1, aerosol=a.aerosol)
+                plan8 = sdist.GatherPlan(w4["B"], 8, sdist.expected_orders(w4["tau_atm"] + w4["taer"], w4["rho"]))
+                shard = np.asarray(plan8.mine(0))
+                c4s = extra_case(O, dev, local_rank, len(shard), 200, 128, a.aerosol, 20, [0, len(shard) - 1], sweep=take(w4, shard))
+                c4s["columns_of_the_sweep"] = [int(x) for x in shard[:4]] + ["..."] + [int(x) for x in shard[-2:]]
+                c4s["implied_8gpu_strong_ceiling"] = {"columns_per_s": 512 / (c4s["ms_per_solve"] * 1e-3),
+                                                      "speedup_over_this_gpu": 512 / (c4s["ms_per_solve"] * 1e-3) / value,
+                                                      "efficiency": 512 / (c4s["ms_per_solve"] * 1e-3) / value / 8,
+                                                      "note": "512 columns / the slowest shard's solve, gather not included; NOT a measurement of 8 GPUs"}
+                ex["c4_shard"] = c4s
+                if a.aerosol != "hg":                    # rounds 1-2 measured the HG(0.7) stand-in: the same sweep shape, for continuity
+                    ex["c4_hg"] = extra_case(O, dev, local_rank, 512, 200, 128, "hg", 5, [0])
+                    ex["c4_hg"]["order_loop"] = "the library's choice (two column groups)"
             except Exception as e:                      # an extra must not take the headline line with it
                 ex["error"] = "%s: %s" % (type(e).__name__, e)
             out["extras"] = ex
+        if world == 1:
+            out["strong"] = {"status": "unmeasured: one GPU.  With --gpus N this object holds the one-sweep-over-the-node measurement of "
+                                       "BASELINE configs[3] (512 columns dealt to the ranks, fields gathered to rank 0)",
+                             "single_gpu_proxy": "extras.c4_shard"}
+        elif strong_obj is not None:
+            out["strong"] = strong_obj
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)

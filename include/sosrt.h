@@ -56,6 +56,11 @@ typedef struct sosrt_handle sosrt_t;
                                               reference's file computes -- non-default, parity unpinned            */
 
 const char* sosrt_last_error(void);
+/* 100 * major + minor of the ABI this library was built from.  101 (round 4): sosrt_set_stream(h, NULL) names the legacy default
+ * stream (100 read NULL as "the handle's own stream"); the per-handle launch plan (sosrt_plan_launch) and the order loop that
+ * runs several orders per launch (sosrt_set_order_loop) were added.  A binding checks sosrt_version() >= the SOSRT_VERSION it
+ * was written against. */
+#define SOSRT_VERSION 101
 int sosrt_version(void);
 
 /* ---- handle ------------------------------------------------------------------------------- */
@@ -120,6 +125,19 @@ int sosrt_set_first_order(sosrt_t* h, int mode);
 #define SOSRT_CONTRACT_F64_FULL 2
 #define SOSRT_SYMMETRY_TOL 1e-12
 int sosrt_set_contraction(sosrt_t* h, int mode);
+
+/* The order loop of spec:309-458 runs an order as two launches (source function, transport) and the host learns the live count
+ * between them.  Once few columns of a batch (or column group) are left -- their transport workgroups at most half the CUs --
+ * the REMAINING orders run in ONE launch whose workgroups keep their roles (csrc/order_loop.hip): the chunk-parallel transport
+ * of each live column and, on all other workgroups, the tiles of the live columns' source functions, tied by per-column
+ * counters in device memory; the host only waits for the launch's report.  Same arithmetic, same bits.  mode 0 (default): never --
+ * measured on MI355X the launch is bit-identical but SLOWER than the two launches per order it replaces (the dependency chain
+ * sweep -> source-function tile -> sweep is the same; DESIGN section 5 item 9, profiles/r04_order_loop_ab_v0.txt); mode 1: where
+ * the launch plan says so (sosrt_plan_launch), kept for the measurements and as the scaffold of a finer-grained pipeline.  The launch checks its own residency first and hands the orders back
+ * to the two-launch loop when another process's kernels keep its grid from being resident (sosrt_order_loop_stats: launches of
+ * the last solve, how many of them were refused that way, and the (column, order) pairs that ran inside them). */
+int sosrt_set_order_loop(sosrt_t* h, int mode);
+int sosrt_order_loop_stats(sosrt_t* h, int* launches, int* refused, long long* column_orders /* nullable: (column, order) pairs run inside them; synchronises */);
 /* asymmetry of the folded matrices of the last sosrt_set_phase (see above); *uses_symmetry: what the next solve will do */
 int sosrt_phase_asymmetry(sosrt_t* h, double* asymmetry, int* uses_symmetry);
 
@@ -247,13 +265,30 @@ int sosrt_plan_fold(sosrt_t* h, int which /*0 atm, 1 aer*/, double* W_out /*2N x
  * C_out [idx][ns] (ns <= 5). */
 int sosrt_plan_fix_table(sosrt_t* h, int idx, int* s0, int* ns, double* C_out);
 int sosrt_plan_fix_count(double tau_ref, int N);  /* I1_In:124-127 */
+/* The kernels an order of the order loop launches, as sosrt_solve_dev decides it (one function of the handle's shape and knobs;
+ * needs sosrt_set_grid only): a batch of `batch` columns with up to `zones` zones each (3: the reference's clear / slab / clear)
+ * over `surface`, of whose first column group `live` columns are still live, on a device of `cus` CUs (0: the handle's).
+ * out[9] = { column groups of the batch, SOSRT_PLAN_GEMM_*, capacity of the live-column contraction (0: dense tiling),
+ *            SOSRT_PLAN_TRANSPORT_*, workgroups per column of the chunk-parallel transport, 1 if the general kernel follows as
+ *            a repair pass, 1 if this and all later orders go into one order-loop launch, its transport workgroups per
+ *            column, its grid }. */
+#define SOSRT_PLAN_GEMM_DENSE        0   /* 64-row tiles over the batch's row lists (tiles of converged columns leave at once) */
+#define SOSRT_PLAN_GEMM_LIVE64       1   /* tiles laid over the live columns, 64 rows                                           */
+#define SOSRT_PLAN_GEMM_LIVE32       2   /* ... 32 rows (at most 200 live columns)                                              */
+#define SOSRT_PLAN_GEMM_LIVE32_DEEP  3   /* ... both operands staged two chunks ahead (at most 32 live columns)                */
+#define SOSRT_PLAN_TRANSPORT_GENERAL 0   /* kernels.hip k_transport                                                             */
+#define SOSRT_PLAN_TRANSPORT_FAST    1   /* transport_fast.hip (odd N, N > 256)                                                 */
+#define SOSRT_PLAN_TRANSPORT_RING    3   /* transport_ring.hip                                                                  */
+#define SOSRT_PLAN_TRANSPORT_SCAN    4   /* transport_scan.hip (chunk-parallel)                                                 */
+int sosrt_plan_launch(sosrt_t* h, int batch, int live, int surface, int zones, int cus, int* out /*[9]*/);
 
 /* ---- profiling: HIP-event timing of the dominant kernels on the handle's stream ------------- */
 #define SOSRT_K_GEMM      0
 #define SOSRT_K_TRANSPORT 1
 #define SOSRT_K_FIRST     2
 #define SOSRT_K_SMALLMU   3
-#define SOSRT_K_COUNT     4
+#define SOSRT_K_ORDER_LOOP 4  /* the order-loop launches (several orders of a few columns each) */
+#define SOSRT_K_COUNT     5
 int sosrt_profile_enable(sosrt_t* h, int on);
 int sosrt_profile_reset(sosrt_t* h);
 /* total milliseconds and launch count since the last reset (synchronises the stream) */

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -72,7 +73,8 @@ struct sosrt_handle {
     // and ran the ring two slots deep, so that a transport workgroup of the other group fits beside them on every CU.  With round 3's
     // kernels the uncapped contraction and a three-slot ring are faster under two groups (alternating runs: 512 columns 4.81 -> 4.75 ms,
     // 1024 columns 8.45 -> 8.15, 384 columns unchanged): the groups share the GPU CU by CU rather than inside a CU.
-    int coresident_pad = 0;             // SOSRT_GEMM_PAD_LDS
+    int coresident_pad = 0;             // SOSRT_GEMM_PAD_LDS (diagnostic builds)
+    int diag_ks_mult = 1;               // SOSRT_GEMM_KS_MULT (diagnostic builds)
     int coresident_slots = 3;           // SOSRT_GROUP_RING_SLOTS: ring depth of the transport under two groups
     double stagger = 1.0;                // a group starts when the previous one is down to this fraction of live columns (SOSRT_STAGGER; 1: together)
     int gb[kMaxGroups + 1] = {0, 0, 0};                    // column range of group g: [gb[g], gb[g+1])
@@ -161,6 +163,17 @@ struct sosrt_handle {
     int last_max_orders = 0;
     long long last_sum_orders = 0;
     Prof prof[kMaxGroups];               // per column group (= per stream)
+    // order-loop kernel (order_loop.hip): the last orders of a few live columns in one launch
+    // (OFF by default: measured on MI355X it is bit-identical and slower -- a lone column 54.6 us per order against 47.0 with two
+    // launches, 64 columns 137 against 50: the chain sweep -> tile of the next source function -> sweep is the same either way,
+    // what the launches cost (~8 us per order) the polls and the write-through hand-offs cost too, and the contraction role has one
+    // four-wave team per CU; profiles/r04_order_loop_ab_v0.txt)
+    int order_loop = 0;                  // sosrt_set_order_loop / SOSRT_ORDER_LOOP: 0 never (default), 1 where the launch plan says so
+    double ol_frac = 0.5;                // ... while the transport workgroups of the live columns are at most this share of the grid
+    int* d_olsync = nullptr;             // [kMaxGroups][order_loop_sync_ints(kOrderLoopMaxCols)] words of a launch
+    int* h_oldone = nullptr;             // pinned [kMaxGroups][2]: {state, tag} reported by the launch's last workgroup
+    int ol_launches = 0, ol_refused = 0; // launches of the last solve; launches that found their grid not resident
+    bool ol_group_used[kMaxGroups] = {false, false};      // column groups of the last solve that ran (to the end) in an order-loop launch
     // RCCL communicator of the sharded solve (sosrt_comm_init)
     Rccl::comm_t comm = nullptr;
     int comm_rank = -1, comm_world = 0;
@@ -370,9 +383,12 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
     }
     if (use_sym(h)) {
         ga.sym = 1; ga.Ks = (h->g.N + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
-        // diagnostic (timing only; the results do not change: the extra chunks multiply zeros): SOSRT_GEMM_KS_MULT=2 doubles the
-        // chunks per tile at the same prologue / epilogue, which separates the two (tile time = P + chunks * C)
-        if (const char* ev = getenv("SOSRT_GEMM_KS_MULT")) { const int m = atoi(ev); if (m > 1 && ga.Ks * m <= h->g.Dp) ga.Ks *= m; }
+#ifdef SOSRT_DIAG
+        // diagnostic builds (timing only; the results do not change: the extra chunks multiply zeros): SOSRT_GEMM_KS_MULT=2 doubles
+        // the chunks per tile at the same prologue / epilogue, which separates the two (tile time = P + chunks * C); read once,
+        // at sosrt_create
+        if (h->diag_ks_mult > 1 && ga.Ks * h->diag_ks_mult <= h->g.Dp) ga.Ks *= h->diag_ks_mult;
+#endif
         ga.Wa = h->d_Wa_s; ga.Wr = h->d_Wr_s;
         if (ga.Wmix) ga.Wmix = h->d_Wmix_s;
     }
@@ -404,12 +420,122 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
     prof_end(h, SOSRT_K_GEMM, pg);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Launch plan: which kernels run an order of a column group.  One function, host only -- it reads the handle's shape and
+// knobs and touches no device -- so that the policy can be read in one place and tested without a GPU (sosrt_plan_launch).
+// ---------------------------------------------------------------------------------------------
+struct SolveShape {                      // what a solve fixes for all its orders (from the grid and the batch's zone tables)
+    bool ring_like = false;              // the ring / chunk-parallel kernels take the batch (they hold its zone tables)
+    bool fast = false;                   // a wave-independent kernel runs (else the general kernel)
+    int nzcap = kRingZones;              // most zones of any column, at least three
+    int ring_mode = 1;                   // 3: ring-class kernels, 1: the register-streaming kernel
+};
+SolveShape solve_shape(const sosrt_handle* h, int max_nz) {
+    SolveShape sh;
+    // The ring / chunk-parallel kernels take columns of any zone count (an instantiation that tests every boundary of the zone
+    // table, chosen when the batch holds such a column); the register-streaming kernel knows three zones, so a batch with more
+    // goes to the general kernel where that one would run (odd N, N > 256).
+    sh.ring_like = h->transport_mode >= 2 && h->ring_ok && (max_nz <= kRingZones || transport_ring_fits(h->g, max_nz));
+    sh.fast = h->transport_mode >= 1 && h->fast_ok && (max_nz <= kRingZones || sh.ring_like);
+    sh.nzcap = max_nz > kRingZones ? max_nz : kRingZones;
+    sh.ring_mode = (h->transport_mode >= 2 && h->ring_ok) ? 3 : 1;
+    return sh;
+}
+struct OrderInputs {                     // what the plan of one order depends on besides the handle
+    int nb = 0;                          // columns of the group
+    int known = 0;                       // upper bound of its live columns (the host's count lags by one order)
+    int surface = SOSRT_SURFACE_NONE;
+    bool simple_zones = true;            // every column is (clear, slab, clear), or a single slab
+    bool slabs_mixed = true;             // slab rows have their combined matrices (or there are none)
+    bool need_small = false;             // some |mu| < 0.01 lane keeps its k_smallmu value
+    bool saving = false;                 // the caller wants every order's field (I_saved)
+    int orders_left = 1 << 30;           // order budget from this order on
+    int cu_share = 0;                    // CUs an order-loop launch of this group may take (0: none)
+};
+struct LaunchPlan {
+    int tail_cols = 0;                   // contraction over the live columns: capacity of the launch (0: dense tiling over the row lists)
+    int gemm = SOSRT_PLAN_GEMM_DENSE;
+    int transport = SOSRT_PLAN_TRANSPORT_GENERAL;
+    int parts = 1;                       // chunk-parallel kernel: workgroups per column
+    int repair = 0;                      // register-streaming kernel: the general kernel behind it for searches that leave wave 0
+    int order_loop = 0;                  // this and every later order of the group in ONE order-loop launch
+    int ol_parts = 0;                    // ... workgroups per column of its transport role
+    int ol_grid = 0;                     // ... workgroups of the launch
+};
+LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderInputs& in) {
+    LaunchPlan pl;
+    const Grid& g = h->g;
+    // contraction: the tilings over the live columns whenever some column has converged -- and for a small batch from the
+    // start: their 32-row tiles put a few columns on more CUs than the dense tiling's 64-row tiles; same bits either way.
+    // (the float contraction has the dense tiling only: no live list for the transport either)
+    const bool live_tiling = h->contraction != SOSRT_CONTRACT_F32 && in.simple_zones && in.known <= h->gemm_tail_cols &&
+                             (in.known <= h->gemm_tail_frac * in.nb || in.nb <= h->gemm_small_cols) &&
+                             (in.known < in.nb || in.nb <= h->gemm_small_cols);
+    pl.tail_cols = live_tiling ? in.known : 0;
+    pl.gemm = !live_tiling ? SOSRT_PLAN_GEMM_DENSE
+                           : (pl.tail_cols <= h->gemm_small_cols ? ((use_sym(h) && pl.tail_cols <= 32) ? SOSRT_PLAN_GEMM_LIVE32_DEEP : SOSRT_PLAN_GEMM_LIVE32)
+                                                                 : SOSRT_PLAN_GEMM_LIVE64);
+    // transport
+    if (!sh.fast) {
+        pl.transport = SOSRT_PLAN_TRANSPORT_GENERAL;
+    } else {
+        const int cols_now = pl.tail_cols > 0 ? pl.tail_cols : in.nb;
+        // chunk-parallel kernel: a column on ceil(N / 64) CUs (two at N = 128, four at N = 256) while that many workgroups per
+        // live column fit the device at once (the reflection must stay inside a part)
+        const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= h->cu_count &&
+                               (in.surface == SOSRT_SURFACE_SPECULAR || in.surface == SOSRT_SURFACE_NONE);
+        const bool want_scan = h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols);
+        const bool scan = sh.ring_mode == 3 && want_scan &&
+                          ((h->scan_ok && transport_scan_fits(g, sh.nzcap, false)) || (can_split && transport_scan_fits(g, sh.nzcap, true)));
+        pl.transport = scan ? SOSRT_PLAN_TRANSPORT_SCAN : (sh.ring_mode == 3 ? SOSRT_PLAN_TRANSPORT_RING : SOSRT_PLAN_TRANSPORT_FAST);
+        if (scan && can_split && transport_scan_fits(g, sh.nzcap, true)) pl.parts = transport_scan_parts(g);
+        pl.repair = (h->N - 3 > 61 && pl.transport == SOSRT_PLAN_TRANSPORT_FAST) ? 1 : 0;
+    }
+    // order-loop kernel: the remaining orders in one launch once the live columns' transport workgroups are a small share of the
+    // CUs it may take (the other workgroups contract).  It holds the chunk-parallel transport (three zones, no kept k_smallmu
+    // lane) and the symmetric contraction's live-column tiles; the default transport policy only (a forced kernel stays forced).
+    if (h->order_loop && in.cu_share > 0 && h->transport_mode == 3 && sh.fast && sh.ring_mode == 3 && sh.nzcap <= kRingZones &&
+        use_sym(h) && in.simple_zones && in.slabs_mixed && !in.saving && !in.need_small && in.orders_left >= 1 &&
+        in.known <= kOrderLoopMaxCols) {
+        Grid gt = g;
+        gt.nsmall = 0;
+        const bool split_ok = h->scan_split && (in.surface == SOSRT_SURFACE_SPECULAR || in.surface == SOSRT_SURFACE_NONE) && order_loop_ok(gt, true);
+        const int sp = order_loop_parts(gt, true);
+        if (split_ok && sp * in.known <= h->ol_frac * in.cu_share) {
+            pl.order_loop = 1; pl.ol_parts = sp;
+        } else if (order_loop_ok(gt, false) && in.known <= h->ol_frac * in.cu_share) {
+            pl.order_loop = 1; pl.ol_parts = 1;
+        }
+        if (pl.order_loop) pl.ol_grid = in.cu_share;
+    }
+    return pl;
+}
+
+// CUs of a device that order-loop launches of this process hold (their workgroups wait for each other, so every one of them must
+// be resident: the launches of all handles together never ask for more workgroups than the device has CUs)
+std::mutex g_ol_mutex;
+int g_ol_held[64];
+int ol_acquire(int device, int total, int want, int least) {
+    if (device < 0 || device >= 64) return 0;
+    std::lock_guard<std::mutex> lk(g_ol_mutex);
+    int got = total - g_ol_held[device];
+    if (got > want) got = want;
+    if (got < least || got <= 0) return 0;
+    g_ol_held[device] += got;
+    return got;
+}
+void ol_release(int device, int n) {
+    if (device < 0 || device >= 64 || n <= 0) return;
+    std::lock_guard<std::mutex> lk(g_ol_mutex);
+    g_ol_held[device] -= n;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* sosrt_last_error(void) { return g_err.c_str(); }
-int sosrt_version(void) { return 100; }
+int sosrt_version(void) { return SOSRT_VERSION; }
 
 int sosrt_plan_fix_count(double tau_ref, int N) { return fix_count(tau_ref, N); }
 
@@ -432,6 +558,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;
     h->saved_slots = max_orders;
     h->gpu = device >= 0;
+    h->cu_count = 256;                       // (a host-only handle plans for an MI355X; a device handle asks the device below)
     if (const char* ev = getenv("SOSRT_ETAB")) h->use_etab = atoi(ev);
     if (const char* ev = getenv("SOSRT_CONTRACT"))            // "full": the D x D product whatever the symmetry of the matrices
         if (strcmp(ev, "full") == 0) h->contraction = SOSRT_CONTRACT_F64_FULL;
@@ -444,11 +571,15 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : (atoi(ev) == 1 ? 1 : 0);      // column groups of the order loop (0: auto)
     if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
+#ifdef SOSRT_DIAG   // measurement knobs of DESIGN section 5 (items 1, 5, 8): diagnostic builds only (-DSOSRT_DIAG), never in the product library
     if (const char* ev = getenv("SOSRT_STAGGER")) h->stagger = atof(ev);
     if (const char* ev = getenv("SOSRT_GROUP_SPLIT")) h->split_at = atoi(ev);
     if (const char* ev = getenv("SOSRT_GROUP_PRIO")) h->prio2 = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_PAD_LDS")) h->coresident_pad = atoi(ev);
+    if (const char* ev = getenv("SOSRT_GEMM_KS_MULT")) h->diag_ks_mult = atoi(ev);
+#endif
     if (const char* ev = getenv("SOSRT_GROUP_RING_SLOTS")) h->coresident_slots = atoi(ev);
+    if (const char* ev = getenv("SOSRT_ORDER_LOOP")) h->order_loop = atoi(ev) != 0;           // (A/B: 0 = every order as two launches)
     if (const char* ev = getenv("SOSRT_RING_SLOTS")) g_ring_slots = atoi(ev);
 #ifdef SOSRT_RING_DEBUG   // diagnostic builds only: the switches make the ring kernel skip work, its results are wrong
     if (const char* ev = getenv("SOSRT_RING_DEBUG")) g_ring_debug = atoi(ev);
@@ -518,6 +649,9 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
             if ((e = dalloc(&h->d_ratio, mb))) return e;
             if ((e = dalloc(&h->d_scan_scratch, mb * transport_scan_scratch_doubles()))) return e;
             if ((e = dalloc(&h->d_scan_sync, 2 * mb))) return e;
+            if ((e = dalloc(&h->d_olsync, sosrt_handle::kMaxGroups * order_loop_sync_ints(kOrderLoopMaxCols)))) return e;
+            HIPCHK(hipHostMalloc((void**)&h->h_oldone, 2 * sosrt_handle::kMaxGroups * sizeof(int), hipHostMallocCoherent));
+            memset(h->h_oldone, 0, 2 * sosrt_handle::kMaxGroups * sizeof(int));
             HIPCHK(hipMemset(h->d_scan_sync, 0, 2 * mb * sizeof(int)));
             HIPCHK(hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, device));
             // + 2 ints at the end: {needs k_smallmu, tag} published at the start of a solve
@@ -549,10 +683,11 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive_sets, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_scan_scratch, h->d_scan_sync, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr};
+                        h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_scan_scratch, h->d_scan_sync, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr, h->d_olsync};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
+        if (h->h_oldone) hipHostFree(h->h_oldone);
 
         for (auto& p : h->prof)
             for (auto& e : p.ev) hipEventDestroy(e);
@@ -603,6 +738,62 @@ int sosrt_set_contraction(sosrt_t* h, int mode) {
         h->w32_dirty = true;
     }
     h->contraction = mode;
+    return 0;
+}
+
+int sosrt_set_order_loop(sosrt_t* h, int mode) {
+    if (!h) return fail(SOSRT_E_INVALID, "null handle");
+    if (mode != 0 && mode != 1) return fail(SOSRT_E_INVALID, "order-loop mode must be 0 or 1 (got %d)", mode);
+    h->order_loop = mode;
+    return 0;
+}
+
+int sosrt_order_loop_stats(sosrt_t* h, int* launches, int* refused, long long* column_orders) {
+    if (!h) return fail(SOSRT_E_INVALID, "null handle");
+    if (launches) *launches = h->ol_launches;
+    if (refused) *refused = h->ol_refused;
+    if (column_orders) {
+        *column_orders = 0;
+        if (h->gpu && h->ol_launches > 0) {             // every launch of the last solve left its count in its group's words
+            HIPCHK(hipSetDevice(h->device));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
+            for (int k = 0; k < sosrt_handle::kMaxGroups; ++k) {
+                if (!h->ol_group_used[k]) continue;
+                int v = 0;
+                HIPCHK(hipMemcpy(&v, h->d_olsync + (size_t)k * order_loop_sync_ints(kOrderLoopMaxCols) + kOlOrders, sizeof v, hipMemcpyDeviceToHost));
+                *column_orders += v;
+            }
+        }
+    }
+    return 0;
+}
+
+int sosrt_plan_launch(sosrt_t* h, int batch, int live, int surface, int zones, int cus, int* out) {
+    if (!h || !out) return fail(SOSRT_E_INVALID, "null argument");
+    if (!h->have_grid) return fail(SOSRT_E_STATE, "sosrt_set_grid has not been called");
+    if (batch < 1 || live < 0 || live > batch) return fail(SOSRT_E_INVALID, "need 0 <= live <= batch, batch >= 1");
+    if (zones < 1 || zones > kMaxZones) return fail(SOSRT_E_INVALID, "zones must be in 1..%d", kMaxZones);
+    // as sosrt_set_columns and the order loop of sosrt_solve_dev see a batch of `batch` (clear, slab, clear)-like columns with up to
+    // `zones` zones: the column groups, then the plan of an order of the first group with `live` columns of it live
+    int want = h->want_groups;
+    if (want == 0) want = batch > h->split_min ? 2 : 1;
+    const int ng = (want >= 2 && batch >= h->split_min && batch >= 2) ? 2 : 1;
+    const int nb = ng == 2 ? batch / 2 : batch;
+    const int saved_cus = h->cu_count;
+    if (cus > 0) h->cu_count = cus;
+    const SolveShape sh = solve_shape(h, zones);
+    OrderInputs oi;
+    oi.nb = nb; oi.known = live < nb ? live : nb; oi.surface = surface;
+    oi.simple_zones = zones == 3 || zones == 1;
+    oi.cu_share = h->cu_count / ng;
+    const bool saved_sym = h->sym_ok;
+    if (!h->have_phase) h->sym_ok = true;            // (no matrices yet: plan for flip-symmetric ones, what every phase function of the scattering angle gives)
+    const LaunchPlan pl = plan_order(h, sh, oi);
+    h->sym_ok = saved_sym;
+    h->cu_count = saved_cus;
+    out[0] = ng; out[1] = pl.gemm; out[2] = pl.tail_cols; out[3] = pl.transport; out[4] = pl.parts; out[5] = pl.repair;
+    out[6] = pl.order_loop; out[7] = pl.ol_parts; out[8] = pl.ol_grid;
     return 0;
 }
 
@@ -662,10 +853,12 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
         h->g.nsmall = (int)h->plan.small_lanes.size();
         if (h->g.nsmall)
             HIPCHK(hipMemcpy(h->d_small, h->plan.small_lanes.data(), h->g.nsmall * sizeof(int), hipMemcpyHostToDevice));
-        h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
-        h->scan_ok = h->ring_ok && transport_scan_ok(h->g);
-        h->scan_split_ok = h->ring_ok && transport_scan_split_ok(h->g);      // (N in (128, 256]: the chunk-parallel kernel has this form only)
     }
+    // which kernels take this shape (pure functions of the grid: a host-only handle answers sosrt_plan_launch with them)
+    h->g.nsmall = (int)h->plan.small_lanes.size();
+    h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
+    h->scan_ok = h->ring_ok && transport_scan_ok(h->g);
+    h->scan_split_ok = h->ring_ok && transport_scan_split_ok(h->g);      // (N in (128, 256]: the chunk-parallel kernel has this form only)
     return 0;
 }
 
@@ -696,9 +889,8 @@ int sosrt_set_phase(sosrt_t* h, const double* P_atm, const double* P_aer) {
             const double r = wmax > 0 ? amax / wmax : 0.0;
             if (!(r <= h->asymmetry)) h->asymmetry = r;
         }
-        double tol = SOSRT_SYMMETRY_TOL;
-        if (const char* ev = getenv("SOSRT_SYMMETRY_TOL")) tol = atof(ev);
-        h->sym_ok = h->asymmetry <= tol;
+        // (a compile-time constant: nothing in the environment can put the symmetric form on a matrix without the symmetry)
+        h->sym_ok = h->asymmetry <= SOSRT_SYMMETRY_TOL;
     }
     if (h->gpu) {
         HIPCHK(hipSetDevice(h->device));
@@ -1062,18 +1254,15 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     su.n_zero = sosrt_handle::kMaxGroups + 1;
     su.redo = h->d_redo;
     su.hash = h->d_tauhash;
+    su.scan_sync = h->d_scan_sync;
     launch_prepare(s, g, B, h->geom, h->surface, scalars_of(h), d_tau, h->d_desc, h->d_rca, h->d_rcr,
                    h->d_nactive + sosrt_handle::kMaxGroups, su);
     h->need_small = true;
     const int small_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;       // never equals an order tag
     bool small_published = false;
-    // The ring / chunk-parallel kernels take columns of any zone count (round 3: an instantiation that tests every boundary of the
-    // zone table, chosen when the batch holds such a column); the register-streaming kernel knows three zones, so a batch with more
-    // goes to the general kernel where that one would run (odd N, N > 256).
-    const bool ring_like = h->transport_mode >= 2 && h->ring_ok && (h->max_nz <= kRingZones || transport_ring_fits(h->g, h->max_nz));
-    const bool fast = h->transport_mode >= 1 && h->fast_ok && (h->max_nz <= kRingZones || ring_like);
-    const int nzcap = h->max_nz > kRingZones ? h->max_nz : kRingZones;
-    const int ring_mode = (h->transport_mode >= 2 && h->ring_ok) ? 3 : 1;
+    const SolveShape shape = solve_shape(h, h->max_nz);
+    const bool fast = shape.fast;
+    const int nzcap = shape.nzcap;
     if (h->use_etab || fast) {
         // one attenuation table per distinct optical-depth profile
         launch_tau_groups(s, g, B, d_tau, h->d_tauhash, h->d_erep, h->d_nactive + sosrt_handle::kMaxGroups,
@@ -1087,8 +1276,15 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     }
     // an error return after the fork still joins the internal stream back onto the caller's
+    int ol_held[sosrt_handle::kMaxGroups] = {0, 0};          // CUs this solve's order-loop launches hold (ol_acquire)
     auto bail = [&](int code) {
         if (NG > 1 && hipEventRecord(h->ev_join, h->stream2) == hipSuccess) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+        for (int k = 0; k < NG; ++k)
+            if (ol_held[k]) {                                 // (a launch still running keeps its CUs until its stream has drained)
+                (void)hipStreamSynchronize(group_stream(h, k));
+                ol_release(h->device, ol_held[k]);
+                ol_held[k] = 0;
+            }
         return code;
     };
 
@@ -1102,9 +1298,15 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     struct GroupState {
         int b0 = 0, nb = 0, n = 1, known = 0;
         bool done = false, started = false;
+        bool ol_pending = false, ol_off = false;             // an order-loop launch is running; one was refused: no more in this solve
+        int ol_tag = 0;
+        unsigned ol_polls = 0;
         double *In_1 = nullptr, *In = nullptr;
         Conv cv;
     } gs[sosrt_handle::kMaxGroups];
+    h->ol_launches = 0; h->ol_refused = 0;
+    for (bool& u : h->ol_group_used) u = false;
+    bool used_order_loop = false;
     const int tagbase = ((++h->pub_seq) & 0x3fff) << 16;      // tag of order n = tagbase + n
     for (int k = 0; k < NG; ++k) {
         GroupState& q = gs[k];
@@ -1151,9 +1353,46 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     }
     int live_groups = NG, n_max = 1;
     while (live_groups > 0) {
+        bool progressed = false;
         for (int k = 0; k < NG; ++k) {
             GroupState& q = gs[k];
             if (q.done) continue;
+            if (q.ol_pending) {
+                // the group's remaining orders run in one launch; its last workgroup reports {state, tag} to pinned memory
+                volatile int* dw = h->h_oldone + 2 * k;
+                if (__atomic_load_n(&dw[1], __ATOMIC_ACQUIRE) != q.ol_tag) {
+                    if ((++q.ol_polls & 0x3fff) != 0) continue;
+                    const hipError_t qe = hipStreamQuery(group_stream(h, k));
+                    if (qe != hipSuccess && qe != hipErrorNotReady) return bail(fail(SOSRT_E_HIP, "order loop: %s", hipGetErrorString(qe)));
+                    if (qe == hipSuccess && __atomic_load_n(&dw[1], __ATOMIC_ACQUIRE) != q.ol_tag)
+                        return bail(fail(SOSRT_E_HIP, "order loop: the order-loop launch ended without reporting"));
+                    continue;
+                }
+                const int state = dw[0];
+                q.ol_pending = false;
+                ol_release(h->device, ol_held[k]);
+                ol_held[k] = 0;
+                progressed = true;
+                if (state == kOlReady) { q.done = true; --live_groups; h->ol_group_used[k] = true; continue; }
+                if (state == kOlAborted) {
+                    // never expected: say where the launch stood (the words of the launch, first columns)
+                    std::vector<int> w(order_loop_sync_ints(q.known < 6 ? q.known : 6));
+                    (void)hipStreamSynchronize(group_stream(h, k));
+                    (void)hipMemcpy(w.data(), h->d_olsync + (size_t)k * order_loop_sync_ints(kOrderLoopMaxCols), w.size() * sizeof(int), hipMemcpyDeviceToHost);
+                    std::string cols;
+                    for (int c = 0; c < (q.known < 6 ? q.known : 6); ++c) {
+                        char buf[96];
+                        const int* cs = w.data() + kOlCols + c * kOlColStride;
+                        snprintf(buf, sizeof buf, " [%d: orders %d stop %d tiles %d]", c, cs[kOlOrdDone], cs[kOlColStop], cs[kOlJnDone]);
+                        cols += buf;
+                    }
+                    return bail(fail(SOSRT_E_HIP, "order loop: a workgroup of the order-loop launch gave up waiting (arrived %d, left %d, order %d on, %d columns:%s)",
+                                     w[kOlArrive], w[kOlLeft], q.n + 1, q.known, cols.c_str()));
+                }
+                // not resident (another process's kernels held CUs): nothing was touched; the one-order kernels take over
+                q.ol_off = true;
+                ++h->ol_refused;
+            }
             if (!q.started) {
                 // Staggered start: the dense orders of this group (they fill the GPU) run beside the long tail of the
                 // previous one (a few workgroups per order, latency-bound), instead of both being dense, then both in
@@ -1162,6 +1401,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 if (!(p.done || (p.n >= 2 && p.known <= h->stagger * p.nb))) continue;
                 start_group(k);
             }
+            progressed = true;
             if (q.n >= h->max_orders) { q.done = true; --live_groups; continue; }
             if (q.n >= 2) {
                 const int live = wait_published(h, k, tagbase + q.n - 1);
@@ -1169,19 +1409,66 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 if (live == 0) { q.done = true; --live_groups; continue; }
                 q.known = live;
             }
-            const int n = ++q.n;
-            n_max = n > n_max ? n : n_max;
             hipStream_t sg = group_stream(h, k);
             const size_t fo = (size_t)q.b0 * LD;
-            // this launch also publishes the group's live count after order n-1
-            // (the float contraction has the dense tiling only: no live list for the transport either)
-            // (the tilings over the live columns whenever some column has converged -- and for a small batch from the start:
-            // their 32-row tiles put a few columns on more CUs than the dense tiling's 64-row tiles; same bits either way)
-            const int tail_cols = (h->contraction != SOSRT_CONTRACT_F32 && h->simple_zones && q.known <= h->gemm_tail_cols &&
-                                   (q.known <= h->gemm_tail_frac * q.nb || q.nb <= h->gemm_small_cols) &&
-                                   (q.known < q.nb || q.nb <= h->gemm_small_cols)) ? q.known : 0;
-            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb);
             const double* tau_g = d_tau + (size_t)q.b0 * h->L;
+            const int* erep_g = h->d_erep + q.b0;     // values are whole-batch column ids; the table base is not offset
+            // ---- the plan of this order (plan_order: one place for the whole policy) ----
+            OrderInputs oi;
+            oi.nb = q.nb; oi.known = q.known; oi.surface = h->surface;
+            oi.simple_zones = h->simple_zones; oi.slabs_mixed = h->nslab == 0 || h->mix_groups > 0;
+            oi.need_small = g.nsmall > 0 && h->need_small; oi.saving = d_I_saved_out != nullptr;
+            oi.orders_left = h->max_orders - q.n;
+            oi.cu_share = q.ol_off ? 0 : h->cu_count / NG;
+            LaunchPlan pl = plan_order(h, shape, oi);
+            if (pl.order_loop) {
+                // its workgroups wait for each other: they must all fit the CUs no other order-loop launch of this process holds
+                const int got = ol_acquire(h->device, h->cu_count, pl.ol_grid, (int)(pl.ol_parts * q.known / h->ol_frac));
+                if (got == 0) { oi.cu_share = 0; pl = plan_order(h, shape, oi); }
+                else { pl.ol_grid = got; ol_held[k] = got; }
+            }
+            if (pl.order_loop) {
+                OrderLoopArgs oa;
+                Grid gt = g;
+                gt.nsmall = 0;
+                oa.t = TransportArgs{gt, tau_g, h->d_Jn + fo, nullptr, d_I_out + fo, nullptr, 0, h->d_desc + q.b0, q.cv, 0, 1, h->d_E, erep_g, nullptr};
+                oa.t.nzcap = kRingZones;
+                oa.t.scan_split = pl.ol_parts > 1 ? 1 : 0;
+                oa.t.scan_scratch = h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles();
+                oa.t.scan_sync = h->d_scan_sync + 2 * q.b0;
+                GemmArgs& ga = oa.gm;
+                ga.A = nullptr; ga.Wa = h->d_Wa_s; ga.Wr = h->d_Wr_s; ga.ca = h->d_rca; ga.cr = h->d_rcr;
+                ga.D = g.D; ga.Dp = g.Dp; ga.Wld = g.Wld; ga.L = h->L; ga.C = h->d_Jn;
+                ga.sym = 1; ga.Ks = (g.N + GEMM_KC - 1) / GEMM_KC * GEMM_KC;
+                ga.max_main = h->max_main; ga.max_slab = h->max_slab;
+                ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
+                if (h->mix_groups > 0) { ga.Wmix = h->d_Wmix_s; ga.mix_group = h->d_mixgroup; }
+                oa.in0 = q.In_1;
+                oa.gbufP = q.In;
+                oa.gbufQ = (q.In_1 == d_I_out) ? h->d_InA : q.In_1;   // (after the second order: the buffer the first order left unused)
+                oa.bufP = oa.gbufP + fo; oa.bufQ = oa.gbufQ + fo;
+                oa.order0 = q.n + 1; oa.kmax = h->max_orders - q.n;
+                oa.B = q.nb; oa.col0 = q.b0;
+                oa.fixcap = (int)(0.06 * g.N) + 1;
+                oa.sync = h->d_olsync + (size_t)k * order_loop_sync_ints(kOrderLoopMaxCols);
+                oa.host_done = h->h_oldone + 2 * k;
+                oa.tag = q.ol_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;
+                prof_break(h);
+                HIPCHK(hipMemsetAsync(oa.sync, 0, order_loop_sync_ints(q.known) * sizeof(int), sg));
+                prof_begin(h, SOSRT_K_ORDER_LOOP, k);
+                const hipError_t le = launch_order_loop(sg, pl.ol_grid, pl.ol_parts > 1, oa);
+                prof_end(h, SOSRT_K_ORDER_LOOP, k);
+                if (le != hipSuccess) return bail(fail(SOSRT_E_HIP, "order-loop launch failed: %s", hipGetErrorString(le)));
+                q.ol_pending = true;
+                used_order_loop = true;
+                ++h->ol_launches;
+                continue;
+            }
+            const int n = ++q.n;
+            n_max = n > n_max ? n : n_max;
+            // this launch also publishes the group's live count after order n-1
+            const int tail_cols = pl.tail_cols;
+            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb);
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
                 prof_begin(h, SOSRT_K_SMALLMU, k);
                 launch_smallmu(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, h->d_desc + q.b0, q.cv.active);
@@ -1189,27 +1476,16 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             }
             prof_begin(h, SOSRT_K_TRANSPORT, k);
             double* sv_n = (d_I_saved_out && n <= h->saved_slots) ? d_I_saved_out + (size_t)q.b0 * saved_stride + (size_t)(n - 1) * LD : nullptr;
-            const int* erep_g = h->d_erep + q.b0;     // values are whole-batch column ids; the table base is not offset
             if (fast) {
                 // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
                 // need not stage those rows either
-                // the kernel of this launch: the chunk-parallel one while few columns are live (same bits as the ring kernel)
-                const int cols_now = tail_cols > 0 ? tail_cols : q.nb;
-                // chunk-parallel kernel: a column on ceil(N / 64) CUs (two at N = 128, four at N = 256) while that many
-                // workgroups per live column fit the device at once (the reflection must stay inside a part)
-                const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= h->cu_count &&
-                                       (h->surface == SOSRT_SURFACE_SPECULAR || h->surface == SOSRT_SURFACE_NONE);
-                const bool want_scan = h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols);
-                const int fast_mode = (ring_mode == 3 && want_scan && ((h->scan_ok && transport_scan_fits(g, nzcap, false)) ||
-                                                                       (can_split && transport_scan_fits(g, nzcap, true)))) ? 4 : ring_mode;
                 Grid gt = g;
-                if (fast_mode >= 3 && !h->need_small) gt.nsmall = 0;
-                const int split = (fast_mode == 4 && can_split && transport_scan_fits(g, nzcap, true)) ? 1 : 0;
+                if (pl.transport >= SOSRT_PLAN_TRANSPORT_RING && !h->need_small) gt.nsmall = 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
-                                 h->d_E, fast_mode, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0, split,
-                                 h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(), h->d_scan_sync + 2 * q.b0,
-                                 nzcap);
-                if (h->N - 3 > 61 && fast_mode == 1)     // register-streaming kernel: a search that leaves wave 0 is redone by the
+                                 h->d_E, pl.transport, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0,
+                                 pl.parts > 1 ? 1 : 0, h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(),
+                                 h->d_scan_sync + 2 * q.b0, nzcap);
+                if (pl.repair)                           // register-streaming kernel: a search that leaves wave 0 is redone by the
                     launch_transport(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
                                      h->d_E, 2, erep_g);         // general kernel (flag cv.redo); the ring kernel redoes it itself
             } else {
@@ -1220,6 +1496,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             if (q.In_1 == d_I_out) { q.In_1 = q.In; q.In = h->d_InA; }      // (after the second order: the buffer the first order left unused)
             else { double* tmp = q.In_1; q.In_1 = q.In; q.In = tmp; }
         }
+        if (!progressed) __builtin_ia32_pause();      // (every live group is inside its order-loop launch)
     }
     if (NG > 1) {                                    // back onto the caller's stream
         HIPCHK(hipEventRecord(h->ev_join, h->stream2));
@@ -1228,7 +1505,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
     prof_break(h);
     launch_finalize(s, B, make_conv(h, tol), h->max_orders, d_n_orders_out, d_status_out);
     HIPCHK(hipGetLastError());
-    h->last_max_orders = n_max;
+    h->last_max_orders = used_order_loop ? -1 : n_max;      // (orders run inside an order-loop launch: read back with the counts)
     h->last_sum_orders = -1;
     return 0;
 }
@@ -1267,8 +1544,10 @@ int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, cons
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, h->d_status, B * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         long long sum = 0;
-        for (int b = 0; b < B; ++b) { sum += no[b] - 1; if (n_orders_out) n_orders_out[b] = no[b]; }
+        int mx = 1;
+        for (int b = 0; b < B; ++b) { sum += no[b] - 1; mx = no[b] > mx ? no[b] : mx; if (n_orders_out) n_orders_out[b] = no[b]; }
         h->last_sum_orders = sum;
+        if (h->last_max_orders < 0) h->last_max_orders = mx;
         h->resident = true; h->resident_B = B;
         return 0;
     };
@@ -1280,13 +1559,15 @@ int sosrt_solve(sosrt_t* h, int B, const double* tau, const double* P0_atm, cons
 
 int sosrt_last_solve_stats(sosrt_t* h, int* max_orders_run, long long* sum_orders) {
     if (int e = need_gpu(h)) return e;
-    if (h->last_sum_orders < 0 && h->B > 0) {
+    if ((h->last_sum_orders < 0 || h->last_max_orders < 0) && h->B > 0) {
         std::vector<int> no(h->B);
         HIPCHK(hipMemcpyAsync(no.data(), h->d_norders, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         long long sum = 0;
-        for (int v : no) sum += v - 1;
+        int mx = 1;
+        for (int v : no) { sum += v - 1; mx = v > mx ? v : mx; }
         h->last_sum_orders = sum;
+        if (h->last_max_orders < 0) h->last_max_orders = mx;
     }
     if (max_orders_run) *max_orders_run = h->last_max_orders;
     if (sum_orders) *sum_orders = h->last_sum_orders;

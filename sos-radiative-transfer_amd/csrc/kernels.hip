@@ -88,6 +88,7 @@ __global__ void k_prepare(Grid g, int B, int geom, int surface, ColScalars sc, c
     // second wave hashes the column's optical-depth profile (the tau groups of k_tau_rep).
     if (su.zero_next && b == 0 && threadIdx.x < su.n_zero) su.zero_next[threadIdx.x] = 0;
     if (su.redo && threadIdx.x == 0) su.redo[b] = 0;
+    if (su.scan_sync && threadIdx.x < 2) su.scan_sync[2 * b + threadIdx.x] = 0;     // {arrivals, flags}: a solve that ended in an error may have left them set
     if (su.hash && threadIdx.x >= 64) {
         const int lane = threadIdx.x - 64;
         const unsigned long long* t = reinterpret_cast<const unsigned long long*>(tau + (size_t)b * g.L);
@@ -180,6 +181,7 @@ void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, 
 // direction m = N + j; the layer loop is sequential only because each zone starts from the
 // attenuated last row of the previous one ("scatt_before", spec:147,176,240,270).
 // ------------------------------------------------------------------------------------------
+constexpr double kFactorMax = 1e150;    // largest zone constant the one-exponential factorisation of k_first_order is used with
 __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const double* __restrict__ P0a_all,
                               const double* __restrict__ P0r_all, const ColDesc* __restrict__ desc,
                               double* __restrict__ I1_all, double* __restrict__ I_all, double* __restrict__ saved,
@@ -254,12 +256,19 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             // e^{(tt - t_bs)/mu} = e^{(tt - t_bd)/mu} e^{(t_bd - t_bs)/mu}.  One fp64 exponential per element instead of two (the
             // kernel is bound by them); the product is
             // within 2 ulp of the direct evaluation, far inside the parity bar.
+            // (ks = e^{+dtau/|mu|} of the layer above the zone: it overflows where that layer is optically thick for the direction --
+            // dtau/|mu| > 709, e.g. a thin thick slab at N = 256 -- while x underflows, and the product would be NaN where the
+            // direct value is at most 1.  Such directions evaluate the second exponential directly; kFactorMax keeps the product
+            // form well inside the range in which neither factor has lost bits.)
             const double ks = exp((t_bd - t_bs) / mu);
+            const bool ks_ok = ks < kFactorMax;
             auto row = [&](int t) {
                 const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
                 // ((tt - t_bd) rmu instead of (tt - t_bd) / mu: one rounding of the argument more, |argument| x 1e-16 relative in
                 // the exponential -- inside its own rounding; the division was a fifth of the kernel)
-                const double x = exp((tt - t_bd) * rmu), xs = x * ks;
+                const double x = exp((tt - t_bd) * rmu);
+                double xs = x * ks;
+                if (!ks_ok) xs = exp((tt - t_bs) * rmu);
                 const double before = z ? Ib * x : 0.0;
                 const double direct = near ? q * F0 * e0 * (tt - t_bd) / mu0 : gd * q * F0 * (e0 - e_bd * x);
                 const double surf = gs * qm * R * (eT - e_bs * xs);
@@ -314,12 +323,15 @@ __global__ void k_first_order(Grid g, const double* __restrict__ tau_all, const 
             const int r0 = d.r0[z], r1 = d.r1[z];
             // (one exponential per element, as in the downward half: the other two attenuations are that one times a factor
             // of the zone and the direction; above the bottom zone t_bb = t_bu)
+            // (above the bottom zone ksu = e^{+dtau/mu} of the layer below the zone: the same overflow as ks of the downward half)
             const double ku = bottom ? exp(-(t_bu - t_bb) / mu) : 1.0, ksu = exp(-(t_su - t_bb) / mu);
+            const bool ksu_ok = ksu < kFactorMax;
             auto row = [&](int t) {
                 const double tt = s_tau[t], e0 = s_e0[t], eT = s_eT[t];
                 const double yb = exp(-(t_bb - tt) * rmu);
                 const double yu = bottom ? yb * ku : yb;
-                const double ys = yb * ksu;
+                double ys = yb * ksu;
+                if (!ksu_ok) ys = exp(-(t_su - tt) * rmu);
                 const double before = Bv * yb;
                 const double direct = gd * q * F0 * (e0 - e_bu * yu);
                 const double surf = near ? qm * R * eT * (t_su - tt) / mu0 : gs * qm * R * (eT - e_su * ys);

@@ -138,6 +138,13 @@ bool transport_scan_fits(const Grid& g, int nzcap, bool split);
 int transport_scan_parts(const Grid& g);                       // workgroups per column of the split form: ceil(N / 64)
 size_t transport_scan_scratch_doubles();                       // per column
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a);
+// order_loop.hip: the last orders of a few live columns in ONE launch (transport and contraction as roles of its workgroups)
+constexpr int kOrderLoopMaxCols = 256;                 // live columns a launch takes at most
+// words of the launch in global memory (ints, zeroed before the launch): launch-wide ones on lines of their own, then per live column
+constexpr int kOlArrive = 0, kOlState = 32, kOlLeft = 64, kOlAbort = 96, kOlOrders = 100, kOlCols = 128;
+constexpr int kOlColStride = 64, kOlOrdDone = 0, kOlColStop = 1, kOlJnDone = 32;
+constexpr int kOlReady = 1, kOlNotResident = 2, kOlAborted = 3;            // state of a launch, as reported to the host
+inline size_t order_loop_sync_ints(int cols) { return (size_t)kOlCols + (size_t)cols * kOlColStride; }
 extern int g_ring_slots, g_ring_debug;                        // tuning (SOSRT_RING_SLOTS)
 extern unsigned long long* g_transport_stamps;   // diagnostics (sosrt_debug_stamps)
 
@@ -147,6 +154,7 @@ struct SolveSetup {
     int n_zero = 0;
     int* redo = nullptr;                 // [B] per-column redo flags, cleared
     unsigned long long* hash = nullptr;  // [B] hash of the column's optical-depth profile
+    int* scan_sync = nullptr;            // [B][2] exchange words of the chunk-parallel transport's split form, cleared
 };
 void launch_prepare(hipStream_t s, const Grid& g, int B, int geom, int surface, ColScalars sc, const double* tau,
                     ColDesc* desc, double* rowcoef_a, double* rowcoef_r, int* need_small = nullptr, SolveSetup su = SolveSetup());
@@ -208,6 +216,25 @@ __device__ inline void publish_live(const GemmArgs& g) {
     }
 }
 void launch_gemm(hipStream_t s, const GemmArgs& a);
+struct OrderLoopArgs {
+    TransportArgs t;           // the column group's view (every per-column pointer offset to its first column): g, tau, Jn, I, desc, cv, Etab, erep, scan_scratch, scan_sync
+    GemmArgs gm;               // the batch's view (whole-batch pointers, global column ids): folded matrices, Wmix, mix_group, idx_up / idx_down, ca / cr, C = Jn
+    const double* in0;         // operand of the launch's first contraction (whole batch)
+    double* gbufP;             // In of the launch's odd / even orders (whole batch) ...
+    double* gbufQ;
+    double* bufP;              // ... and the same from the group's first column
+    double* bufQ;
+    int order0;                // scattering order n of the launch's first order
+    int kmax;                  // orders the launch runs at most
+    int B, col0;               // the group's columns: [col0, col0 + B) of the batch
+    int fixcap;
+    int* sync;                 // order_loop_sync_ints(cap) zeroed ints
+    int* host_done;            // pinned {status, tag}
+    int tag;
+};
+bool order_loop_ok(const Grid& g, bool split);
+int order_loop_parts(const Grid& g, bool split);
+hipError_t launch_order_loop(hipStream_t s, int grid, bool split, const OrderLoopArgs& p);
 // jn_gemm_f32.hip: the contraction with float operands and a float accumulator (opt-in, tolerance study)
 void launch_gemm_f32(hipStream_t s, const GemmArgs& a, const float* Wa32, const float* Wmix32);
 void launch_to_float(hipStream_t s, size_t n, const double* src, float* dst);

@@ -31,6 +31,14 @@ __device__ __forceinline__ double bload_glc(__amdgpu_buffer_rsrc_t r, int voff, 
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 1);
     return __hiloint2double((int)v.y, (int)v.x);
 }
+// the same with a cache policy (aux bits of the raw buffer intrinsics on gfx940+: 1 = sc0, 16 = sc1): 16 = an agent-scope load,
+// past this CU's L1 -- for rows another workgroup of the same launch has stored write-through (bstore_aux<17>), or this
+// workgroup itself an order ago (order_loop.hip)
+template <int AUX>
+__device__ __forceinline__ double bload_aux(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x) {
     u32x2 v;
     v.x = (unsigned)__double2loint(x);
@@ -51,6 +59,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // two adjacent doubles per lane (16 bytes): half the vector-memory instructions of the 8-byte forms
 __device__ __forceinline__ double2 bload2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+template <int AUX>
+__device__ __forceinline__ double2 bload2_aux(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
     return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
 }
 __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, int voff, int soff, double2 x) {
@@ -196,7 +209,9 @@ __device__ __forceinline__ void flag_row(int* s_nf, int t) { atomicOr(&s_nf[t >>
 #else
 #define SOSRT_HELPER_INLINE __forceinline__
 #endif
-template <bool ACC, bool SAVED>
+// LDX / STX: cache policy of the field rows' loads and stores (0: as the one-order kernels have it -- loads past the L1 with
+// `glc`, plain stores; the order-loop kernel passes 16 / 17, see bload_aux)
+template <bool ACC, bool SAVED, int LDX = 0, int STX = 0>
 __device__ SOSRT_HELPER_INLINE bool finish_flagged_rows(const int* s_nf, int L, int N, int RB, const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rIn,
                                     __amdgpu_buffer_rsrc_t rI, __amdgpu_buffer_rsrc_t rS, double* s_work, double& rup_v, double& rup_i) {
     const int tid = threadIdx.x, NP = N + 2;
@@ -223,8 +238,8 @@ __device__ SOSRT_HELPER_INLINE bool finish_flagged_rows(const int* s_nf, int L, 
 #pragma unroll
         for (int i = 0; i < kNfBatch; ++i) {                    // the rows as the sweep left them, past the L1
             const int t = s_list[c0 + min(i, nb - 1)];
-            xo[i] = bload_glc(rIn, vo, t * RB);
-            Io[i] = ACC ? bload_glc(rI, vo, t * RB) : 0.0;
+            xo[i] = bload_aux<LDX ? LDX : 1>(rIn, vo, t * RB);
+            Io[i] = ACC ? bload_aux<LDX ? LDX : 1>(rI, vo, t * RB) : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < kNfBatch; ++i)
@@ -247,13 +262,13 @@ __device__ SOSRT_HELPER_INLINE bool finish_flagged_rows(const int* s_nf, int L, 
             const int t = s_list[c0 + i];
             if (tr && tid < kf) {                               // spec:407-409
                 const double x = blend_val(blend_weight(mu, 1.0 / gmu[N + kf]), r[0], r[kf]);
-                bstore(rIn, vo, t * RB, x);
+                bstore_aux<STX>(rIn, vo, t * RB, x);
                 double It = 0;
                 if (ACC) {
                     It = Io[i] + (x - xo[i]);
-                    bstore(rI, vo, t * RB, It);
+                    bstore_aux<STX>(rI, vo, t * RB, It);
                 }
-                if (SAVED) bstore(rS, vo, t * RB, x);
+                if (SAVED) bstore_aux<STX>(rS, vo, t * RB, x);
                 if (t == 0) { rup_v = x; rup_i = It; }
             }
         }
@@ -271,7 +286,7 @@ __device__ SOSRT_HELPER_INLINE bool finish_flagged_rows(const int* s_nf, int L, 
 // 650 us for a 200-row column that the rest of its launch then waited for).
 // s_work: kRedoRows-independent, 2 N + 4 doubles.  Returns true if some row has no stop at all (IndexError, spec:404).
 constexpr int kRedoRows = 8;
-template <bool ACC, bool SAVED, bool MZ>
+template <bool ACC, bool SAVED, bool MZ, int LDX = 0, int STX = 0>
 __device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, const ZoneRows<MZ>& zr, const double* s_hd,
                                   const double* __restrict__ gmu, __amdgpu_buffer_rsrc_t rJ, __amdgpu_buffer_rsrc_t rE,
                                   __amdgpu_buffer_rsrc_t rIn, __amdgpu_buffer_rsrc_t rI, __amdgpu_buffer_rsrc_t rS, double U0,
@@ -294,10 +309,10 @@ __device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, cons
 #pragma unroll
         for (int u = 0; u < kRedoRows; ++u) {
             const int t = max(t0 - u, 0);
-            Jc[u] = bload(rJ, vo, t * RB);
+            Jc[u] = bload_aux<LDX>(rJ, vo, t * RB);
             Ec[u] = bload(rE, vo, t * RB);
-            xo[u] = bload_glc(rIn, vo, t * RB);
-            Io[u] = ACC ? bload_glc(rI, vo, t * RB) : 0.0;
+            xo[u] = bload_aux<LDX ? LDX : 1>(rIn, vo, t * RB);
+            Io[u] = ACC ? bload_aux<LDX ? LDX : 1>(rI, vo, t * RB) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < kRedoRows; ++u) {
@@ -320,13 +335,13 @@ __device__ SOSRT_HELPER_INLINE bool redo_upward_sweep(int L, int N, int RB, cons
             U = (zone_start && tr) ? x : Un;
             Jnext = Jc[u];
             if (act) {
-                bstore(rIn, vo, t * RB, x);
+                bstore_aux<STX>(rIn, vo, t * RB, x);
                 double It = 0;
                 if (ACC) {
                     It = Io[u] + (x - xo[u]);
-                    bstore(rI, vo, t * RB, It);
+                    bstore_aux<STX>(rI, vo, t * RB, It);
                 }
-                if (SAVED) bstore(rS, vo, t * RB, x);
+                if (SAVED) bstore_aux<STX>(rS, vo, t * RB, x);
                 if (t == 0) { rup_v = x; rup_i = It; }
             }
             par ^= 1;

@@ -14,7 +14,9 @@ SOSRT_OK, E_INVALID, E_HIP, E_STATE, E_NOMEM = 0, -1, -2, -3, -4
 COL_OK, COL_INDEXERROR, COL_MAXORDERS, COL_INTERNAL = 0, 1, 2, 3
 GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
 SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN, SURFACE_LAMBERTIAN_README = 0, 1, 2, 3
-K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU = 0, 1, 2, 3
+K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU, K_ORDER_LOOP = 0, 1, 2, 3, 4
+PLAN_GEMM_DENSE, PLAN_GEMM_LIVE64, PLAN_GEMM_LIVE32, PLAN_GEMM_LIVE32_DEEP = 0, 1, 2, 3
+PLAN_TRANSPORT_GENERAL, PLAN_TRANSPORT_FAST, PLAN_TRANSPORT_RING, PLAN_TRANSPORT_SCAN = 0, 1, 3, 4
 CONTRACT_F64, CONTRACT_F32, CONTRACT_F64_FULL = 0, 1, 2
 FIRST_ORDER_CODED, FIRST_ORDER_README = 0, 1
 PHASE_ISO, PHASE_RAYLEIGH, PHASE_HG, PHASE_TABLE = 0, 1, 2, 3
@@ -34,6 +36,9 @@ SIGNATURES = {
     "sosrt_set_saved_orders": (c_int, [c_void_p, c_int]),
     "sosrt_set_contraction": (c_int, [c_void_p, c_int]),
     "sosrt_phase_asymmetry": (c_int, [c_void_p, POINTER(c_double), _ip]),
+    "sosrt_set_order_loop": (c_int, [c_void_p, c_int]),
+    "sosrt_order_loop_stats": (c_int, [c_void_p, _ip, _ip, POINTER(c_longlong)]),
+    "sosrt_plan_launch": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, _ip]),
     "sosrt_set_first_order": (c_int, [c_void_p, c_int]),
     "sosrt_set_grid": (c_int, [c_void_p, c_void_p]),
     "sosrt_set_phase": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -187,6 +187,11 @@ def solve_sharded(mu0, tauStar_aer, grd_alb, *, group=None, dst=0, device=None, 
             sub[k] = np.asarray(sub[k])[mine]
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
+    # what the device-resident solve does not carry must not be dropped silently
+    if sub.get("first_order", "coded") != "coded":
+        raise ValueError("solve_sharded solves with the coded first order only (first_order=%r)" % (sub["first_order"],))
+    if sub.get("save_orders"):
+        raise ValueError("solve_sharded does not return I_saved (save_orders=True): the per-order fields stay on the ranks")
     for k in ("raise_on_error", "save_orders", "devices", "first_order"):
         sub.pop(k, None)
     L, N = int(kw.get("nb_layers", 200)), int(kw.get("nb_angles", 128))
@@ -209,6 +214,9 @@ def solve_sharded(mu0, tauStar_aer, grd_alb, *, group=None, dst=0, device=None, 
         pack = torch.cat([loc["I"].reshape(len(mine), -1), loc["tau"], loc["n"].to(torch.float64)[:, None],
                           loc["status"].to(torch.float64)[:, None]], dim=1)
         got = gather_rows(pack, plan, dst=dst, group=group, key="pack", via="abi", solver=s)
+        # the cached solver goes back to its own stream (as solve_batch_device leaves it), once the gather has left this one
+        torch.cuda.current_stream(tdev).synchronize()
+        s.set_stream(None)
         if rank == dst:
             got = plan.restore(got)
             LD = L * 2 * N

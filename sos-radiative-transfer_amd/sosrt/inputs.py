@@ -117,18 +117,20 @@ def _bulk(name, **kw):
     return _bulk_cache[key]
 
 
-def scenario_table(name, lambda0=None, indx=None, r_m=None, sig=None):
+def scenario_table(name, lambda0=None, indx=None, r_m=None, sig=None, indx_convention="absorbing"):
     """The (mu_diff, p) table of 'eva' | 'wildfire' (README.md:95-111 unless overridden): what `phase_function` evaluates on
     the host and `phase_function_device` hands to the device table kernel (SOSRT_PHASE_TABLE).  Parity unpinned (own Mie
-    series, sosrt/mie.py)."""
+    series, sosrt/mie.py).  `indx_convention`: how the sign of Im(indx) is read -- 'absorbing' (default: any imaginary part
+    absorbs), 'n+ik', 'n-ik' (miepython's documented sign); sosrt/mie.py."""
     kw = dict(_mie.SCENARIOS[name])
     for k, v in (("wl", lambda0), ("m", indx), ("r_m", r_m), ("sig", sig)):
         if v:
             kw[k] = v
-    return _bulk(name, **kw)
+    kw["m"] = _mie.refractive_index(kw["m"], indx_convention)          # (the cache key holds the index as the series takes it)
+    return _bulk(name, convention="n+ik", **kw)
 
 
-def _scalar_phase(name, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None):
+def _scalar_phase(name, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None, indx_convention="absorbing"):
     """p(cos Theta) as a NumPy callable, and -- for the device builders -- its (kind, table) form."""
     if name == "rayleigh":
         return (lambda c: (3 / 4) * (1 + c * c)), ("rayleigh", None)
@@ -138,30 +140,31 @@ def _scalar_phase(name, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=No
         mt, pt = fwc_table() if table is None else (np.asarray(table[0], dtype=np.float64), np.asarray(table[1], dtype=np.float64))
         return (lambda c: interpolate_table(mt, pt, c)), ("table", (mt, pt))
     if name in ("eva", "wildfire"):
-        mt, pt = scenario_table(name, lambda0, indx, r_m, sig)
+        mt, pt = scenario_table(name, lambda0, indx, r_m, sig, indx_convention)
         return (lambda c: interpolate_table(mt, pt, c)), ("table", (mt, pt))
     if name == "mie":
         if not (r and lambda0 and indx):
             raise ValueError("'mie' needs r, lambda0 and indx")
         x = 2 * np.pi * r / lambda0
         mt = np.linspace(-1, 1, 6001)                       # phase:684-694 (compute_P's grid of scattering cosines)
-        pt = _mie.i_unpolarized(complex(indx), x, mt)
+        pt = _mie.i_unpolarized(complex(indx), x, mt, indx_convention)
         return (lambda c: interpolate_table(mt, pt, c)), ("table", (mt, pt))
     raise ValueError("unknown phase function %r" % (name,))
 
 
-def phase_function(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None):
+def phase_function(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None,
+                   indx_convention="absorbing"):
     """'iso' | 'rayleigh' | 'hg' | 'fwc' (SOS_Aer_phase_func.py:68,79,141,238; 'table' = 'fwc' with a caller's
     (mu_tab, p_tab)); 'mie' (one sphere of radius r, :299); 'eva' | 'wildfire' (log-normal ensemble, :398;
     parameters default to the README's scenarios).  Host (NumPy) evaluation."""
     if name == "iso":
         return np.ones(2 * nb_angles), 2 * np.ones((2 * nb_angles, 2 * nb_angles))
-    fn, _ = _scalar_phase(name, g, r, lambda0, indx, r_m, sig, table)
+    fn, _ = _scalar_phase(name, g, r, lambda0, indx, r_m, sig, table, indx_convention)
     return _azimuth_averaged(fn, mu, mu0)
 
 
 def phase_function_device(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None, indx=None, r_m=None, sig=None, table=None,
-                          matrix=True, device=0, solver=None):
+                          matrix=True, device=0, solver=None, indx_convention="absorbing"):
     """The same on the GPU: `mu0` may be an array (one P0 row per column).  Returns (P0 [len(mu0), 2N] or [2N] for a
     scalar mu0, P [2N, 2N] or None when matrix=False).  Every name `phase_function` takes: 'iso' | 'rayleigh' | 'hg' |
     'fwc' | 'table' | 'mie' | 'eva' | 'wildfire' -- the Mie-derived ones as tables on the scattering cosine (the Mie series
@@ -169,7 +172,7 @@ def phase_function_device(name, nb_angles, mu, mu0, g=0.0, r=None, lambda0=None,
     from .solver import Solver
     scalar = np.ndim(mu0) == 0
     m = np.atleast_1d(np.asarray(mu0, dtype=np.float64))
-    kind, tab = ("iso", None) if name == "iso" else _scalar_phase(name, g, r, lambda0, indx, r_m, sig, table)[1]
+    kind, tab = ("iso", None) if name == "iso" else _scalar_phase(name, g, r, lambda0, indx, r_m, sig, table, indx_convention)[1]
     s = solver or Solver(2, nb_angles, max_batch=max(1, min(m.size, 4096)), max_orders=1, device=device)
     try:
         if not s.same_grid(mu):

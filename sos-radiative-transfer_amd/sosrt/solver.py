@@ -89,6 +89,18 @@ class Solver:
             raise ValueError("contraction must be 'f64', 'f64_full' or 'f32'")
         check(lib().sosrt_set_contraction(self._h, m))
 
+    def set_order_loop(self, on=True):
+        """Whether the last orders of the last few live columns run in ONE launch (csrc/order_loop.hip; default on: same
+        bits, no launches and no host round trip per order) or every order stays two launches."""
+        check(lib().sosrt_set_order_loop(self._h, 1 if on else 0))
+
+    def order_loop_stats(self, column_orders=False):
+        """(order-loop launches of the last solve, launches that found their grid not resident and handed back[, the (column,
+        order) pairs that ran inside them -- synchronises])"""
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        check(lib().sosrt_order_loop_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c) if column_orders else None))
+        return (a.value, b.value, c.value) if column_orders else (a.value, b.value)
+
     def phase_asymmetry(self):
         """(max |W[k][m] - W[2N-1-k][2N-1-m]| / max |W| of the folded matrices, whether the next solve uses the symmetry)"""
         a, u = ctypes.c_double(), ctypes.c_int()
@@ -358,6 +370,16 @@ class Solver:
         C = np.zeros((max(idx, 1), 5))
         check(lib().sosrt_plan_fix_table(self._h, int(idx), ctypes.byref(s0), ctypes.byref(ns), _ptr(C)))
         return s0.value, ns.value, C.reshape(-1)[: idx * ns.value].reshape(idx, ns.value).copy()
+
+    def plan_launch(self, batch, live, surface="specular", zones=3, cus=0):
+        """The kernels an order of the order loop launches for a batch of `batch` columns (up to `zones` zones each) of whose
+        first column group `live` are live -- sosrt_plan_launch, the one function the order loop decides with; host only."""
+        sf = {"none": _lib.SURFACE_NONE, "specular": _lib.SURFACE_SPECULAR, "lambertian": _lib.SURFACE_LAMBERTIAN,
+              "lambertian_readme": _lib.SURFACE_LAMBERTIAN_README}[surface]
+        out = (ctypes.c_int * 9)()
+        check(lib().sosrt_plan_launch(self._h, int(batch), int(live), sf, int(zones), int(cus), out))
+        keys = ("groups", "gemm", "tail_cols", "transport", "parts", "repair", "order_loop", "ol_parts", "ol_grid")
+        return dict(zip(keys, list(out)))
 
     def microbench(self, which):
         """0: FP64 MFMA TFLOP/s, 1: streaming copy GB/s, 2: FP64 FMA TFLOP/s, measured on this device."""

@@ -25,6 +25,7 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["unit"] == "columns/s" and d["value"] > 0 and d["dtype"] == "f64"
     assert d["roofline"]["bound"] in ("mfma", "hbm") and 0 < d["roofline"]["frac"] < 1
     assert {d["roofline"]["kernel"], d["roofline_other"]["kernel"]} == {"k_jn_gemm", "k_transport_ring + k_transport_scan"}
+    assert "roofline_order_loop" not in d                  # (the order-loop launches are off by default)
     assert d["config"]["not_converged"] == 0 and d["config"]["columns_per_gpu"] == 64
     # the run checks itself: sampled columns against the oracle, outside the timed region
     assert d["check"]["ok"] and d["check"]["max_rel_err_vs_oracle"] <= 1e-10 and d["check"]["orders_match"]
@@ -39,6 +40,24 @@ def test_bench_single_gpu_line():
     assert abs(tr["work_per_launch"] * tr["launches"] - 32.0 * 200 * 256 * d["config"]["orders_per_step"] * d["steps"]) < 1.0
     rs = d["roofline_step"]
     assert 0 < rs["frac_executed"] <= rs["frac_full_product"] < 1
+    assert d["strong"]["status"].startswith("unmeasured")
+
+
+def test_bench_accounts_for_order_loop_launches():
+    """SOSRT_ORDER_LOOP=1 (opt-in): 216 columns -- the first orders are two launches each; once at most 128 columns are live the
+    rest of the solve is ONE order-loop launch, priced on a line of its own; the (column, order) pairs of a step are in one or
+    the other."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--columns", "216", "--no-cpu-baseline", "--no-extras",
+                        "--pipelined", "0"], cwd=ROOT, env=dict(os.environ, SOSRT_ORDER_LOOP="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["check"]["ok"] and d["config"]["not_converged"] == 0
+    ol = d["roofline_order_loop"]
+    assert ol["kernel"].startswith("k_order_loop") and ol["launches"] == d["steps"] and ol["refused_launches"] == 0
+    for r in (d["roofline"], d["roofline_other"], ol):
+        assert abs(r["achieved"] - r["work_per_launch"] / (r["avg_launch_ms"] * 1e-3) / (1e9 if r["unit"] == "GB/s" else 1e12)) < 1e-6 * r["achieved"]
+    two = [r for r in (d["roofline"], d["roofline_other"]) if not r["kernel"].startswith("k_order_loop")]
+    assert two and all(r["column_orders_per_step"] + ol["column_orders_per_step"] == d["config"]["orders_per_step"] for r in two)
 
 
 def test_bench_extras_c2_c3_c5_and_hg_stand_in():
@@ -69,7 +88,12 @@ def test_bench_two_column_groups_at_the_headline_size():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["check"]["ok"] and d["two_groups"]["same_bits_as_headline"]
-    assert 0.6 < d["two_groups"]["ms_per_step"] / d["ms_per_step"] < 1.25       # (0.94 on a quiet box)
+    # (the ratio is reported, not asserted: 0.94 on a quiet box, but a wall-clock ratio flakes on a busy one -- ADVICE r3)
+    print("two groups / one group: %.3f" % (d["two_groups"]["ms_per_step"] / d["ms_per_step"]))
+    assert d["strong"]["status"].startswith("unmeasured")
+    sh = d["extras"]["c4_shard"]
+    assert sh["check"]["ok"] and sh["workload"].startswith("64 columns") and 0 < sh["implied_8gpu_strong_ceiling"]["efficiency"] < 1
+    assert d["extras"]["c2"]["check"]["ok"] and d["extras"]["c3"]["check"]["ok"] and d["extras"]["c5"]["check"]["ok"]
 
 
 def test_bench_two_ranks_share_the_gpu():
@@ -84,6 +108,10 @@ def test_bench_two_ranks_share_the_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["columns_per_gpu"] == [27, 27] and "cpu_baseline" not in d
     assert len(d["config"]["orders_per_step_per_rank"]) == 2 and d["check"]["ok"]
+    # the same run also measures ONE sweep over the two ranks (BASELINE configs[3]) beside the weak-scaling headline
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["value"] > 0 and st["gather_places_columns"]
+    assert sorted(st["columns_per_gpu"]) == [13, 14]
 
 
 def test_bench_strong_scaling_spawns_its_own_ranks():

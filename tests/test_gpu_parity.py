@@ -455,6 +455,29 @@ def test_first_order_just_outside_the_limit_window():
             assert np.max(np.abs(I1 - ext)) <= 1e-11 * np.max(np.abs(ext))      # absolute: a few 1e-13 on a scale of 0.4
 
 
+@pytest.mark.parametrize("L,N,zs,taer", [(40, 256, (26, 24), 4.0), (40, 256, (60, 24), 60.0), (24, 501, (70, 50), 8.0)])
+def test_first_order_of_an_optically_thick_layer_at_a_zone_edge_stays_finite(L, N, zs, taer):
+    """k_first_order evaluates one exponential per element and gets the row's other attenuations as that one times a constant of
+    the zone and the direction, e^{+dtau/|mu|} of the layer at the zone's edge -- which overflows where that layer is optically
+    thick for the direction (dtau/|mu| > 709: a one-layer slab of tau 4 at N = 256 has 1020 at mu = 1/255) while the exponential
+    underflows: the product was NaN where the direct value is at most 1.  Such directions take the direct
+    exponential; the field stays finite and at the usual bar against the oracle, and so does the whole column."""
+    mu = inputs.direction_grid(N)
+    mu0 = 0.6
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, mu0)
+    P0r, Pr = inputs.phase_function("hg", N, mu, mu0, 0.7)
+    col = O.make_column(mu0, 120, zs[0], zs[1], L, 0.124, taer, 0.3, 1.0, 0.9, N, P0a, Pa, P0r, Pr)
+    edge = (col.tau[col.idx_up] - col.tau[col.idx_up - 1]) / mu[N + 1]
+    assert edge > 745, edge                                   # e^{edge} is inf, e^{-edge} is 0
+    s = Solver(L, N, max_batch=1, max_orders=4)
+    s.set_grid(mu); s.set_phase(Pa, Pr)
+    s.set_columns([col.idx_up], [col.idx_down], mu0, 0.3, 1.0, 0.9, col.dtau_atm, col.dtau_aer, col.tauStar_tot)
+    I1 = s.first_order(col.tau[None], P0a[None], P0r[None])[0]
+    s.close()
+    assert np.isfinite(I1).all()
+    assert_close(I1, O.first_order(col), RTOL, "first order, thick layer at the zone edge")
+
+
 # ----------------------------------------------------------------------------------------------
 # the README's Lambertian first order (non-default option; PARITY UNPINNED -- SURVEY H1: the reference has no runnable
 # code for it).  Device against the oracle's restatement of README.md:126-171, and two properties.

@@ -416,6 +416,45 @@ def test_transport_kernel_follows_the_live_count_with_the_same_bits(monkeypatch)
     fresh()
 
 
+@pytest.mark.parametrize("L,N,B,surface", [(200, 128, 1, "specular"), (200, 128, 24, "specular"), (72, 64, 40, "specular"),
+                                           (200, 256, 3, "specular"), (50, 32, 7, "specular"), (90, 192, 5, "specular"),
+                                           (72, 128, 9, "lambertian"), (41, 100, 6, "specular"), (200, 128, 150, "specular")])
+def test_order_loop_kernel_keeps_the_bits(L, N, B, surface, monkeypatch):
+    """The last orders of the last few live columns in ONE launch (csrc/order_loop.hip: the chunk-parallel transport of each live
+    column and the tiles of their source functions as roles of one grid, tied by per-column counters) against the same solve
+    with every order as two launches: same order counts, same statuses, the same bits -- for a lone column (the launch starts at
+    the second order), for batches that enter it when enough columns have converged, in the split form (two and four
+    workgroups per column), with one workgroup per column (N <= 64, a Lambertian surface) and on shapes whose last part or
+    last chunk is ragged; and the launches really ran."""
+    from sosrt import main as M
+    rng = np.random.default_rng(1000 * L + 7 * N + B)
+    mu0 = rng.uniform(0.2, 1.0, B)
+    taer = rng.choice([0.02, 0.12, 0.6, 1.0], B)
+    rho = rng.uniform(0.0, 0.8, B)
+    kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=L, nb_angles=N, max_orders=200, surface=surface, raise_on_error=False)
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("SOSRT_ORDER_LOOP", on)
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+        out[on] = SOS_Aer_batch(mu0, taer, rho, **kw)
+        launches = [s_.order_loop_stats() for s_ in M._solvers.values()]
+        assert launches, "no cached solver"
+        if on == "1":
+            assert launches[0][0] >= 1 and launches[0][1] == 0, launches        # it ran, and was never refused
+        else:
+            assert launches[0][0] == 0
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a.n, b.n), (a.n, b.n)
+    assert np.array_equal(a.status, b.status)
+    assert (a.status == 0).any()
+    assert np.array_equal(a.I, b.I)                                            # bit for bit
+
+
 @pytest.mark.parametrize("L,N", [(3, 8), (4, 64), (5, 128), (8, 32), (9, 128), (17, 100), (33, 64), (65, 128),
                                  (40, 256), (26, 192), (21, 200), (200, 256)])
 def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):

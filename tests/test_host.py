@@ -129,6 +129,32 @@ def test_mie_series_and_log_normal_ensemble():
     # Bohren & Huffman appendix A test case: m = 1.55, x = 2 pi 0.525 / 0.6328
     qe, qs, qb, g = mie.efficiencies(1.55 + 0j, 2 * np.pi * 0.525 / 0.6328)
     assert (round(qe, 5), round(qs, 5), round(qb, 5), round(g, 5)) == (3.10543, 3.10543, 2.92534, 0.63314)
+    # Wiscombe (1979, NCAR/TN-140+STR, the MIEV0 test cases; the same numbers Bohren & Huffman-style codes are checked with):
+    # (Q_ext, Q_sca, g) to six digits.  The absorbing cases are written m = n - ik there; this module's series takes n + ik.
+    for m, x, (qe_, qs_, g_) in (((1.5 + 0j), 10.0, (2.881999, 2.881999, 0.742913)),
+                                 ((0.75 + 0j), 10.0, (2.232265, 2.232265, 0.896473)),
+                                 ((0.75 + 0j), 1000.0, (1.997908, 1.997908, 0.844944)),
+                                 ((1.5 + 1j), 1.0, (2.336321, 0.663454, 0.192136)),
+                                 ((1.5 + 1j), 100.0, (2.097502, 1.283697, 0.850252)),
+                                 ((10 + 10j), 1.0, (2.532993, 2.049405, -0.110664)),
+                                 ((10 + 10j), 100.0, (2.071124, 1.836785, 0.556215))):
+        qe, qs, _, g = mie.efficiencies(m, x)
+        assert (round(qe, 6), round(qs, 6), round(g, 6)) == (qe_, qs_, g_), (m, x, qe, qs, g)
+    assert mie.efficiencies(0.75 + 0j, 0.099)[0] == pytest.approx(7.417859e-06, rel=1e-6)       # Rayleigh regime
+    assert mie.efficiencies(1.5 + 1j, 0.055)[:2] == pytest.approx((0.101491, 1.1e-05), abs=5e-7)
+    # the sign of Im(m): by default any imaginary part is absorption, so both ways of writing the wildfire aerosol's index
+    # (README.md:109 writes 1.7 + 0.03j; miepython documents n - ik) are the same, absorbing, sphere; the literal conventions
+    # are explicit options, and the wrong one is a gain medium (Q_abs < 0) -- which is why it is never the default
+    a = mie.efficiencies(1.7 + 0.03j, 2.0)
+    assert a == mie.efficiencies(1.7 - 0.03j, 2.0) == mie.efficiencies(1.7 + 0.03j, 2.0, "n+ik") == mie.efficiencies(1.7 - 0.03j, 2.0, "n-ik")
+    assert a[0] > a[1] > 0                                                        # extinction > scattering: it absorbs
+    wrong = mie.efficiencies(1.7 - 0.03j, 2.0, "n+ik")
+    assert wrong[0] < wrong[1]                                                    # "absorption" < 0
+    assert mie.refractive_index(1.7 - 0.03j) == 1.7 + 0.03j and mie.refractive_index(1.7 - 0.03j, "n+ik") == 1.7 - 0.03j
+    with pytest.raises(ValueError):
+        mie.refractive_index(1.5, "whatever")
+    assert np.array_equal(inputs.phase_function("wildfire", 8, inputs.direction_grid(8), 0.5, indx=1.7 - 0.03j)[0],
+                          inputs.phase_function("wildfire", 8, inputs.direction_grid(8), 0.5)[0])
     # Rayleigh limit: p ~ 1 + mu^2
     mu = np.linspace(-1, 1, 9)
     p = mie.i_unpolarized(1.5 + 0j, 0.02, mu)
@@ -153,3 +179,60 @@ def test_mie_series_and_log_normal_ensemble():
     P0e, _ = inputs.phase_function("eva", N, mug, 0.5)
     assert P0e[:N].sum() > 2 * P0e[N:].sum()        # micron-size sulphate scatters forward: sunlight keeps going down
 
+
+
+def test_launch_plan_of_the_order_loop():
+    """sosrt_plan_launch: the one function the order loop of sosrt_solve_dev decides with (csrc/api.hip: plan_order), on
+    host-only handles -- over the direction count, the live count, the surface and the zone count."""
+    T, G = _lib, _lib
+    def plan(N, L, batch, live, order_loop=True, **kw):
+        s = Solver(L, N, device=-1)
+        s.set_grid(inputs.direction_grid(N))
+        s.set_order_loop(order_loop)              # (off by default: measured slower than two launches per order, DESIGN section 5)
+        p = s.plan_launch(batch, live, **kw)
+        s.close()
+        return p
+    assert plan(128, 200, 1, 1, order_loop=False)["order_loop"] == 0 and plan(128, 200, 512, 20, order_loop=False)["order_loop"] == 0
+    # BASELINE C4 shape (L = 200, N = 128), the 512-column sweep: two column groups of 256
+    p = plan(128, 200, 512, 512)
+    assert (p["groups"], p["gemm"], p["transport"], p["order_loop"]) == (2, G.PLAN_GEMM_DENSE, T.PLAN_TRANSPORT_RING, 0)
+    p = plan(128, 200, 512, 180)                    # a few converged (more than 60 % of the group live): the dense tiling skips their tiles
+    assert (p["gemm"], p["tail_cols"], p["transport"]) == (G.PLAN_GEMM_DENSE, 0, T.PLAN_TRANSPORT_RING)
+    p = plan(128, 200, 512, 150)                    # contraction over the live columns, chunk-parallel transport
+    assert (p["gemm"], p["tail_cols"], p["transport"], p["parts"], p["order_loop"]) == (G.PLAN_GEMM_LIVE32, 150, T.PLAN_TRANSPORT_SCAN, 1, 0)
+    p = plan(128, 200, 512, 100)                    # two workgroups per column while they fit the CUs
+    assert (p["transport"], p["parts"], p["order_loop"]) == (T.PLAN_TRANSPORT_SCAN, 2, 0)
+    p = plan(128, 200, 512, 60)                     # the group's share is 128 CUs: 60 columns x 1 workgroup <= half of it
+    assert (p["order_loop"], p["ol_parts"], p["ol_grid"]) == (1, 1, 128)
+    p = plan(128, 200, 512, 30)                     # ... x 2 workgroups
+    assert (p["order_loop"], p["ol_parts"], p["ol_grid"]) == (1, 2, 128)
+    # BASELINE C2 / C3: one column is in the order-loop launch from the second order on, on the whole device
+    assert (plan(128, 200, 1, 1)["order_loop"], plan(128, 200, 1, 1)["ol_parts"], plan(128, 200, 1, 1)["ol_grid"]) == (1, 2, 256)
+    p = plan(256, 200, 1, 1)
+    assert (p["transport"], p["parts"], p["order_loop"], p["ol_parts"]) == (T.PLAN_TRANSPORT_SCAN, 4, 1, 4)
+    assert plan(256, 200, 64, 64)["order_loop"] == 0 and plan(256, 200, 64, 32)["order_loop"] == 1     # 4 x 64 > 128 >= 4 x 32
+    # the 64-column shard of the C4 sweep on one of 8 GPUs: in the launch from the second order on
+    p = plan(128, 200, 64, 64)
+    assert (p["groups"], p["order_loop"], p["ol_parts"], p["ol_grid"]) == (1, 1, 2, 256)
+    assert plan(128, 200, 200, 129)["order_loop"] == 0 and plan(128, 200, 200, 128)["order_loop"] == 1   # one workgroup per column
+    # a Lambertian surface couples all directions at the ground: one workgroup per column, in both kernels
+    p = plan(128, 200, 64, 40, surface="lambertian")
+    assert (p["transport"], p["parts"], p["order_loop"], p["ol_parts"]) == (T.PLAN_TRANSPORT_SCAN, 1, 1, 1)
+    p = plan(256, 200, 8, 8, surface="lambertian")  # ... which N = 256 does not have: ring kernel, no order-loop launch
+    assert (p["transport"], p["order_loop"]) == (T.PLAN_TRANSPORT_RING, 0)
+    # N <= 64: one lane group, one workgroup per column
+    p = plan(32, 50, 1, 1)
+    assert (p["transport"], p["parts"], p["order_loop"], p["ol_parts"]) == (T.PLAN_TRANSPORT_SCAN, 1, 1, 1)
+    # the reference's shipped size (odd N, N > 256): the register-streaming kernel + repair pass; N = 70: the general kernel
+    p = plan(501, 800, 1, 1)
+    assert (p["transport"], p["repair"], p["order_loop"]) == (T.PLAN_TRANSPORT_FAST, 1, 0)
+    assert plan(70, 50, 4, 4)["transport"] == T.PLAN_TRANSPORT_GENERAL
+    # columns of more than three zones (two aerosol layers): ring-class kernels, dense contraction, no order-loop launch
+    p = plan(128, 200, 64, 20, zones=5)
+    assert (p["gemm"], p["transport"], p["order_loop"]) == (G.PLAN_GEMM_DENSE, T.PLAN_TRANSPORT_SCAN, 0)
+    # a smaller device: the launch is sized by its CUs
+    p = plan(128, 200, 16, 16, cus=64)
+    assert (p["order_loop"], p["ol_parts"], p["ol_grid"]) == (1, 2, 64)
+    assert plan(128, 200, 64, 64, cus=64)["order_loop"] == 0
+    with pytest.raises(ValueError):
+        plan(128, 200, 4, 5)
