@@ -485,8 +485,8 @@ LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderIn
         const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= h->cu_count &&
                                (in.surface == SOSRT_SURFACE_SPECULAR || in.surface == SOSRT_SURFACE_NONE);
         const bool want_scan = h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols);
-        const bool scan = sh.ring_mode == 3 && want_scan &&
-                          ((h->scan_ok && transport_scan_fits(g, sh.nzcap, false)) || (can_split && transport_scan_fits(g, sh.nzcap, true)));
+        const bool scan = want_scan && ((sh.ring_mode == 3 && h->scan_ok && transport_scan_fits(g, sh.nzcap, false)) ||
+                                        (can_split && transport_scan_fits(g, sh.nzcap, true)));
         pl.transport = scan ? SOSRT_PLAN_TRANSPORT_SCAN : (sh.ring_mode == 3 ? SOSRT_PLAN_TRANSPORT_RING : SOSRT_PLAN_TRANSPORT_FAST);
         if (scan && can_split && transport_scan_fits(g, sh.nzcap, true)) pl.parts = transport_scan_parts(g);
         pl.repair = (h->N - 3 > 61 && pl.transport == SOSRT_PLAN_TRANSPORT_FAST) ? 1 : 0;
@@ -858,7 +858,9 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
     h->g.nsmall = (int)h->plan.small_lanes.size();
     h->ring_ok = h->fast_ok && transport_ring_ok(h->g);
     h->scan_ok = h->ring_ok && transport_scan_ok(h->g);
-    h->scan_split_ok = h->ring_ok && transport_scan_split_ok(h->g);      // (N in (128, 256]: the chunk-parallel kernel has this form only)
+    // (N in (128, 256]: the chunk-parallel kernel has this form only; it does not need the ring kernel's shape -- odd N, N up to
+    // 512 and L up to 1024 take its WIDE instantiation: the reference's shipped N = 501, L = 800)
+    h->scan_split_ok = h->fast_ok && transport_scan_split_ok(h->g);
     return 0;
 }
 

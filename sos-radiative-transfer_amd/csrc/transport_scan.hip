@@ -6,7 +6,7 @@ namespace sosrt {
 
 namespace {
 
-template <bool ACC, bool SAVED, bool SPLIT, int NC = 0, bool MZ = false>
+template <bool ACC, bool SAVED, bool SPLIT, int NC = 0, bool MZ = false, bool WIDE = false>
 __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fixcap) {
     // SPLIT: ceil(N / 64) workgroups per column (two at N = 128, four at N = 256), part p = blockIdx.x mod that
     const int nparts = SPLIT ? ((NC ? NC : a.g.N) + 63) >> 6 : 1;
@@ -18,7 +18,31 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
     } else if (ACC && !a.cv.active[b]) {
         return;
     }
-    (void)transport_scan_order<ACC, SAVED, SPLIT, NC, MZ, false>(a, fixcap, b, part, ScanFused());
+    (void)transport_scan_order<ACC, SAVED, SPLIT, NC, MZ, false, WIDE>(a, fixcap, b, part, ScanFused());
+}
+
+// shapes of the split form that take its WIDE instantiation (transport_scan_body.hpp): odd N, N > 256, more than 64 chunks per sweep
+inline bool scan_wide(const Grid& g) { return (g.N & 1) || g.N > 256 || (g.L + TC - 1) / TC > 64; }
+
+// the WIDE instantiation of the split form (three zones, with or without saved orders)
+void launch_scan_wide(hipStream_t s, dim3 grid, const TransportArgs& a) {
+    using C = ScanCfg<true, true>;
+    const dim3 block((C::SW + NLOAD) * 64);
+    const size_t shm = scan_lds_bytes<true, true>(a.g, kRingZones);
+#define SOSRT_SCAN_LAUNCH_W(SAVED_)                                                                            \
+    do {                                                                                                       \
+        auto kern = k_transport_scan<true, SAVED_, true, 0, false, true>;                                      \
+        static bool big_lds = false;                                                                           \
+        if (!big_lds) {                                                                                        \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)kScanLdsBytes);                                                           \
+            big_lds = true;                                                                                    \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
+    } while (0)
+    if (a.saved) SOSRT_SCAN_LAUNCH_W(true);
+    else SOSRT_SCAN_LAUNCH_W(false);
+#undef SOSRT_SCAN_LAUNCH_W
 }
 
 template <bool SPLIT>
@@ -68,16 +92,18 @@ bool transport_scan_ok(const Grid& g) {
     if ((g.L + TC - 1) / TC > 64) return false;
     return scan_lds_bytes<false>(g) <= kScanLdsBytes;
 }
-// ceil(N / 64) workgroups per column: at least two lane groups to deal, whole 16-byte lanes in a group's 512 bytes, at most
-// kScanDirs directions per hemisphere (the exchange rows), at most 64 chunks per sweep.  N in (128, 256] has this form only.
+// ceil(N / 64) workgroups per column: at least two lane groups to deal, at most kScanDirs directions per hemisphere (the exchange
+// rows), at most kScanChunks chunks per sweep.  N in (128, 256] has this form only; odd N, N > 256 and L > 512 its WIDE
+// instantiation only (the reference's shipped N = 501, L = 800: eight workgroups per column).
 bool transport_scan_split_ok(const Grid& g) {
-    if (g.N % 2 || g.N <= 64 || g.N > kScanDirs) return false;
-    if ((g.L + TC - 1) / TC > 64) return false;
+    if (g.N <= 64 || g.N > kScanDirs) return false;
+    if (scan_wide(g)) return (g.L + TC - 1) / TC <= kScanChunks && scan_lds_bytes<true, true>(g) <= kScanLdsBytes;
     return scan_lds_bytes<true>(g) <= kScanLdsBytes;
 }
 int transport_scan_parts(const Grid& g) { return (g.N + 63) / 64; }
 // whether the per-zone tables of a batch whose columns have up to nzcap zones still fit beside the stages
 bool transport_scan_fits(const Grid& g, int nzcap, bool split) {
+    if (split && scan_wide(g)) return nzcap <= kRingZones && scan_lds_bytes<true, true>(g) <= kScanLdsBytes;     // (three zones only)
     return (split ? scan_lds_bytes<true>(g, nzcap) : scan_lds_bytes<false>(g, nzcap)) <= kScanLdsBytes;
 }
 size_t transport_scan_scratch_doubles() { return kScanScratch; }
@@ -85,7 +111,8 @@ size_t transport_scan_scratch_doubles() { return kScanScratch; }
 // a.scan_split: two workgroups per column (the grid is then twice the columns; specular surface or none; a.scan_scratch /
 // a.scan_sync: kScanScratch doubles and two zeroed ints per column of the batch)
 void launch_transport_scan(hipStream_t s, dim3 grid, const TransportArgs& a) {
-    if (a.scan_split && a.accumulate) launch_scan_t<true>(s, dim3(transport_scan_parts(a.g) * grid.x), a);
+    if (a.scan_split && a.accumulate && scan_wide(a.g)) launch_scan_wide(s, dim3(transport_scan_parts(a.g) * grid.x), a);
+    else if (a.scan_split && a.accumulate) launch_scan_t<true>(s, dim3(transport_scan_parts(a.g) * grid.x), a);
     else launch_scan_t<false>(s, grid, a);
 }
 

@@ -51,18 +51,25 @@ namespace {
 // downward directions N-64 .. N-1: every mu -> 0 treatment), part 1 the rest -- so that the specular reflection, which maps a
 // downward direction onto its mirror image, stays inside a workgroup, and no workgroup ever waits for another; one lane
 // group x 8 chunk residues.  The arithmetic per direction is the same, so the choice is free (it follows the live count).
-template <bool SPLIT> struct ScanCfg {
+// WIDE (split form only): the instantiation for shapes beyond the BASELINE ones -- an odd direction count (the upward half of a
+// row then starts 8 bytes off a 16-byte boundary: the stages are filled 4 bytes per lane instead of 16), more than 256
+// directions (up to 512: eight workgroups per column), more than 64 chunks per sweep (up to 128: L <= 1024; the masks of the
+// chunks with a zone boundary are two words) -- the reference's shipped N = 501, L = 800 (spec:33,57) is all three.  Ten stages
+// instead of twelve and the |mu| < 0.01 lanes read from memory instead of an LDS table, so that the tables of such a shape
+// fit beside the stages.  Same operations per direction as every other form.
+template <bool SPLIT, bool WIDE = false> struct ScanCfg {
     static constexpr int SW = SPLIT ? 8 : 4;               // waves per lane group = chunks of a sweep in flight
-    static constexpr int NST = SPLIT ? 12 : 6;             // stages: chunk g (0 .. 2 NCH - 1 over the two sweeps) uses stage g mod NST
+    static constexpr int NST = SPLIT ? (WIDE ? 10 : 12) : 6;   // stages: chunk g (0 .. 2 NCH - 1 over the two sweeps) uses stage g mod NST
     static constexpr int SROW = SPLIT ? 64 : 128;          // doubles per staged row (half a 1-KiB half row when split)
     static constexpr int STAGE = (2 * TC + 1) * SROW;      // doubles per stage: Jn, attenuation, + the Jn row before the chunk
 };
 constexpr int NLOAD = 4;                                   // loader waves
 constexpr int CR = 16;                                     // ring of carried values per lane group (> SW)
-constexpr int kScanDirs = 256;                             // most directions per hemisphere of the split form
-constexpr int kScanScratch = 5 * kScanDirs + 8;            // doubles per column of the split form's exchange: 4 test rows + surface row + 16 words of flagged rows
-// (the mask of flagged rows is (L + 31) / 32 ints in those 8 doubles: at most 64 chunks of TC rows per sweep)
-static_assert(64 * TC / 32 <= 16, "the flagged-row mask of the split form's exchange holds 16 ints: 64 chunks of TC rows");
+constexpr int kScanDirs = 512;                             // most directions per hemisphere of the split form
+constexpr int kScanChunks = 128;                           // most chunks per sweep (WIDE; 64 otherwise: one mask word)
+constexpr int kScanScratch = 5 * kScanDirs + 16;           // doubles per column of the split form's exchange: 4 test rows + surface row + 32 words of flagged rows
+// (the mask of flagged rows is (L + 31) / 32 ints in those 16 doubles: at most kScanChunks chunks of TC rows per sweep)
+static_assert(kScanChunks * TC / 32 <= 32, "the flagged-row mask of the split form's exchange holds 32 ints: 128 chunks of TC rows");
 constexpr size_t kScanLdsBytes = 152 * 1024;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned kSpinLimit = 1u << 20;                  // (a carried value arrives within a few thousand polls)
@@ -103,9 +110,11 @@ __device__ __forceinline__ bool fused_wait_ge(const int* p, int want, int* abort
     }
 }
 
-template <bool ACC, bool SAVED, bool SPLIT, int NC = 0, bool MZ = false, bool FUSED = false>
+template <bool ACC, bool SAVED, bool SPLIT, int NC = 0, bool MZ = false, bool FUSED = false, bool WIDE = false>
 __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int fixcap, const int b, const int part, const ScanFused& fu) {
-    constexpr int SW = ScanCfg<SPLIT>::SW, NST = ScanCfg<SPLIT>::NST, SROW = ScanCfg<SPLIT>::SROW, STAGE = ScanCfg<SPLIT>::STAGE;
+    static_assert(!WIDE || (SPLIT && !MZ && !FUSED && NC == 0), "WIDE is an instantiation of the plain split form");
+    using Cfg = ScanCfg<SPLIT, WIDE>;
+    constexpr int SW = Cfg::SW, NST = Cfg::NST, SROW = Cfg::SROW, STAGE = Cfg::STAGE;
     // SPLIT: ceil(N / 64) workgroups per column (two at N = 128, four at N = 256), part p
     const int nparts = SPLIT ? ((NC ? NC : a.g.N) + 63) >> 6 : 1;
     // cache policy of the field rows (see above): loads of data another workgroup (or this one, an order ago) stored; stores
@@ -178,8 +187,8 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
     double* s_fixc = s_sfc + ND;                         // [nzcap][fixcap][kFixMaxSrc] compact extrapolation tables (nzcap: most zones of any column of the batch, >= 3)
     double* s_red = s_fixc + (MZ ? a.nzcap : kRingZones) * fixcap * kFixMaxSrc;    // [nwaves + 2]
     double* s_hd = s_red + nwaves + 2;                         // [L + 1] half layer thicknesses
-    double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu
-    double* s_prmu = s_S + (size_t)g.nsmall * L;               // [16] 1/mu of the first upward directions
+    double* s_S = s_hd + L + 1;                                // [nsmall][L] the |mu| < 0.01 lanes as written by k_smallmu (WIDE: read from memory)
+    double* s_prmu = s_S + (WIDE ? 0 : (size_t)g.nsmall * L);  // [16] 1/mu of the first upward directions
     double* s_conv = s_prmu + 16;                              // [4][ND] last rows of the sweeps: value, running total
     double* s_xw = s_conv + 4 * ND;                      // [ncw][2][TC * 16] per-wave exchange: values, running totals
     // flags (ints): [nwc][CR] sequence number of the carried value in a slot, [NST] chunk landed in a stage,
@@ -209,9 +218,20 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
     const __amdgpu_buffer_rsrc_t rS = make_rsrc(SAVED ? a.saved + (size_t)b * a.saved_col_stride : a.In, SAVED ? fbytes : 0);
 
     // chunks with a zone boundary and the last chunk of each sweep: serial form (one bit per chunk of a sweep)
-    unsigned long long sp_dn = 1ull << (NCH - 1), sp_up = sp_dn;
-    sp_dn |= zr.boundary_chunks(L, TC, false);
-    sp_up |= zr.boundary_chunks(L, TC, true);
+    // (WIDE: up to 128 chunks per sweep, two words each)
+    unsigned long long sp_dn = 0, sp_up = 0, sp_dn1 = 0, sp_up1 = 0;
+    if (!WIDE) {
+        sp_dn = sp_up = 1ull << (NCH - 1);
+        sp_dn |= zr.boundary_chunks(L, TC, false);
+        sp_up |= zr.boundary_chunks(L, TC, true);
+    } else {
+        sp_dn = zr.boundary_chunks(L, TC, false, 0); sp_dn1 = zr.boundary_chunks(L, TC, false, 1);
+        sp_up = zr.boundary_chunks(L, TC, true, 0); sp_up1 = zr.boundary_chunks(L, TC, true, 1);
+        if (NCH - 1 < 64) { sp_dn |= 1ull << (NCH - 1); sp_up |= 1ull << (NCH - 1); }
+        else { sp_dn1 |= 1ull << (NCH - 1 - 64); sp_up1 |= 1ull << (NCH - 1 - 64); }
+    }
+    auto special_dn = [&](int q) __attribute__((always_inline)) { return WIDE ? (((q < 64 ? sp_dn : sp_dn1) >> (q & 63)) & 1) != 0 : ((sp_dn >> q) & 1) != 0; };
+    auto special_up = [&](int j) __attribute__((always_inline)) { return WIDE ? (((j < 64 ? sp_up : sp_up1) >> (j & 63)) & 1) != 0 : ((sp_up >> j) & 1) != 0; };
 
 
     // The value carried into chunk q of this lane group, published by the wave of chunk q - 1.  Plain LDS accesses in
@@ -287,7 +307,26 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
         const int t0 = up ? L - 1 - q * TC : q * TC;
         // byte offset of this workgroup's directions in a row: the half row (1 KiB pieces), or -- split -- its 64 directions (512 B)
         const int half = SPLIT ? (up ? N * 8 + part * 512 : dn0 * 8) : (up ? N * 8 : 0);
-        if (SPLIT) {
+        if (WIDE && (N & 1)) {
+            // An odd direction count: a row is 16 N bytes, so rows start on 16-byte boundaries but their upward halves (and this
+            // part's window of either half) start 8 bytes off one, which the 16-byte form of the LDS-DMA cannot address: the
+            // window goes 4 bytes per lane, two instructions per 512-byte row (34 per chunk instead of 9; the loaders have the
+            // slack -- they are a quarter as busy as the computing waves).  (The second half's 256 bytes go into the scalar
+            // offset: the instruction's immediate offset would move the LDS address as well.)
+            const int v4 = lane * 4;
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const int row = up ? max(t0 - u, 0) : min(t0 + u, L - 1);
+                const int so = row * RB + half;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROW), 4, v4, so, 0, LDX);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (0 * TC + u) * SROW + 32), 4, v4, so + 256, 0, LDX);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROW), 4, v4, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rE, (lds_ptr_t)(dst + (1 * TC + u) * SROW + 32), 4, v4, so + 256, 0, 0);
+            }
+            const int rx = up ? min(t0 + 1, L - 1) : max(t0 - 1, 0);     // the row before the chunk (unused by the first chunk)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROW), 4, v4, rx * RB + half, 0, LDX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_ptr_t)(dst + (2 * TC) * SROW + 32), 4, v4, rx * RB + half + 256, 0, LDX);
+        } else if (SPLIT) {
             // A staged row of the split form is 512 B, half of what one `buffer_load_dwordx4 ... lds` moves: the two halves of
             // the wave take two consecutive rows of the stage (the row offset goes into the per-lane address, the LDS
             // destination is contiguous), 9 instructions per chunk instead of 17: a lone column's launch 32.6 -> 30.6 us
@@ -366,7 +405,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
         }
         if (tid < 4) s_flag[tid] = 0;
         for (int i = tid; i < nwc * CR + NST + NST * nwc + (L + 31) / 32; i += nt) s_flagq[i] = 0;
-        if (!FUSED) {                                           // (FUSED runs only while no |mu| < 0.01 lane keeps its k_smallmu value)
+        if (!FUSED && !WIDE) {                                  // (FUSED runs only while no |mu| < 0.01 lane keeps its k_smallmu value; WIDE reads them from memory)
             const double* __restrict__ In0 = a.In + (size_t)b * L * D;
             for (int i = tid; i < g.nsmall * L; i += nt) {
                 const int k = i / L, t = i - k * L;
@@ -442,7 +481,9 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
             if (((SP && MODE != 3) || MODE == 2) && has_small) {
 #pragma unroll
                 for (int u = 0; u < TC; ++u) {
-                    const double sv = s_S[sbase + min(t0 + u, L - 1)];
+                    // (WIDE: from the field in memory, where k_smallmu left them -- this thread reads its element of a row before
+                    // it stores that element at the end of the chunk)
+                    const double sv = WIDE ? (small ? bload(rIn, vo, min(t0 + u, L - 1) * RB) : 0.0) : s_S[sbase + min(t0 + u, L - 1)];
                     Sc[u] = small ? sv : 0.0;
                 }
             }
@@ -641,7 +682,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
         using M2 = std::integral_constant<int, 2>;
         using M3 = std::integral_constant<int, 3>;
         for (int q = grp; q < NCH; q += SW) {
-            if ((sp_dn >> q) & 1) {
+            if (special_dn(q)) {
                 // fast form when every zone the chunk touches has at most 8 rewritten directions with their sources inside the
                 // 16-lane window (and no |mu| < 0.01 lane keeps its k_smallmu value)
                 bool fastsp = !has_small;
@@ -899,7 +940,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
         using M3 = std::integral_constant<int, 3>;
         // (the general form of the chunks with a zone boundary stays reachable: -DSOSRT_SCAN_GENERAL_SPECIAL builds)
         for (int j = grp; j < NCH; j += SW) {
-            if ((sp_up >> j) & 1) {
+            if (special_up(j)) {
 #ifdef SOSRT_SCAN_GENERAL_SPECIAL
                 chunk(std::true_type{}, M1{}, j);
 #else
@@ -956,7 +997,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
         // write-through in the first place (round 2 left them dirty in its L2: part 0 arriving last read stale rows).
         double* gs = a.scan_scratch + (size_t)b * kScanScratch;            // [4 test rows + surface row][kScanDirs]
         int* sync = a.scan_sync + 2 * b;                                   // {arrivals, flags}
-        int* gnf = reinterpret_cast<int*>(gs + 5 * kScanDirs);             // [16] bit mask of the flagged rows
+        int* gnf = reinterpret_cast<int*>(gs + 5 * kScanDirs);             // [32] bit mask of the flagged rows
         __shared__ int s_last;
         if (wid == 0) {                                                    // (lanes = this workgroup's directions)
             if (valid_dn) {
@@ -1074,12 +1115,12 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
 }
 
 inline int scan_fixcap(const Grid& g) { return (int)(0.06 * g.N) + 1; }
-template <bool SPLIT>
+template <bool SPLIT, bool WIDE = false>
 inline size_t scan_lds_bytes(const Grid& g, int nzcap = kRingZones) {
-    using C = ScanCfg<SPLIT>;
+    using C = ScanCfg<SPLIT, WIDE>;
     const int nwc = SPLIT ? 1 : (g.N + 63) / 64, ncw = nwc * C::SW, nwaves = ncw + NLOAD, ND = (g.N + 63) / 64 * 64;
     const size_t doubles = (size_t)C::NST * C::STAGE + (size_t)nwc * CR * 64 + ND + (size_t)nzcap * scan_fixcap(g) * kFixMaxSrc + nwaves + 2 +
-                           g.L + 1 + (size_t)g.nsmall * g.L + 16 + 4 * ND + (size_t)ncw * 2 * TC * 16;
+                           g.L + 1 + (WIDE ? 0 : (size_t)g.nsmall * g.L) + 16 + 4 * ND + (size_t)ncw * 2 * TC * 16;
     return doubles * sizeof(double) + ((size_t)(nwc * CR + C::NST + C::NST * nwc + (g.L + 31) / 32 + kMaxZones) * sizeof(int) + 7) / 8 * 8;
 }
 

@@ -168,6 +168,17 @@ template <bool MZ> struct ZoneRows {
         return z;
     }
     __device__ __forceinline__ int nfix(int zz) const { return dg->nfix[zz]; }
+    // the same for sweeps of more than 64 chunks: bits of the chunks 64 word .. 64 word + 63 (the reference's zones only)
+    __device__ __forceinline__ unsigned long long boundary_chunks(int L, int tc, bool up, int word) const {
+        unsigned long long m = 0;
+        const int rows[4] = {zend0, zend1, zbeg1, zbeg2};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (up ? L - 1 - rows[i] : rows[i]) / tc;
+            if (rows[i] >= 0 && (c >> 6) == word) m |= 1ull << (c & 63);
+        }
+        return m;
+    }
     // bit q of the result: chunk q of a sweep (TC rows; up: counted from the last row) contains a zone boundary
     __device__ __forceinline__ unsigned long long boundary_chunks(int L, int tc, bool up) const {
         unsigned long long m = 0;

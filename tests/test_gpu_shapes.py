@@ -30,6 +30,12 @@ def _oracle(mu0, taer, rho, L, N, P_atm, P_aer, z_up, z_down, alb_aer, surface="
     (90, 192, (25, 17), [(0.4, 0.12, 0.3)]),                                     # three waves per sweep
     (600, 32, (25, 17), [(0.5, 0.12, 0.15)]),                                    # more than 64 chunks per sweep: every chunk takes the ring kernel's general body
     (520, 64, (60, 30), [(0.6, 0.3, 0.2)]),                                      # 65 chunks, zone boundaries far down
+    # the WIDE instantiation of the chunk-parallel kernel's split form (round 4): odd N, N > 256, more than 64 chunks per sweep
+    (100, 501, (25, 17), [(0.5, 0.12, 0.3), (0.8, 0.6, 0.0)]),                   # the reference's shipped direction count: eight workgroups per column, 4-byte stage fills
+    (96, 300, (40, 20), [(0.6, 0.2, 0.1), (0.3, 1.0, 0.5)]),                     # five workgroups per column, a ragged last part
+    (800, 128, (25, 17), [(0.5, 0.12, 0.15)]),                                   # the shipped layer count at N = 128: 100 chunks per sweep, two mask words
+    (64, 257, (30, 10), [(0.7, 0.3, 0.2), (0.25, 1.0, 0.0)]),                    # odd, one direction into a fifth part
+    (700, 129, (25, 17), [(0.5, 0.12, 0.15)]),                                   # odd N just above two parts, 88 chunks
 ])
 def test_shapes_match_oracle(L, N, zs, cols):
     mu = inputs.direction_grid(N)
@@ -544,6 +550,34 @@ def test_reference_shipped_size_L800_N501():
     one = SOS_Aer(nb_layers=L, nb_angles=N, grd_alb=0.3, P_atm=Pa, P0_atm=P0a, P_aer=Pr, P0_aer=P0r, max_orders=256)
     assert one.I_saved.shape == (ref.n, L, 2 * N) and one.n == ref.n
     assert_close(one.I_saved.sum(axis=0), one.I, 1e-13, "sum of the orders")
+
+
+def test_the_literal_shipped_call():
+    """`SOS_Aer()` with NO arguments: the literals of SOS_Aer_main_specular.py:23-96 -- 800 layers, 501 directions per hemisphere,
+    a perfectly reflecting ground (grd_alb = 1), conservative scattering, Rayleigh + the EVA log-normal Mie aerosol -- up to an
+    order budget of 8 (the column needs 13 orders; the oracle takes 7 s per order at this size), against the oracle on identical
+    (P0, P): same order count, the budget reported, every order's field and their sum at 1e-10.  The transport is the WIDE
+    instantiation of the chunk-parallel kernel (eight workgroups per column), with the |mu| < 0.01 lanes of the thin upper zone
+    kept from k_smallmu (idx = 2 there: directions N-5 .. N-3 survive)."""
+    from sosrt.main import SOS_Aer, DEFAULTS
+    L, N = DEFAULTS["nb_layers"], DEFAULTS["nb_angles"]
+    assert (L, N, DEFAULTS["grd_alb"], DEFAULTS["aer_phase_fun"]) == (800, 501, 1, "eva")
+    from sosrt import main as M
+    for s_ in list(M._solvers.values()):                     # (a cached handle of this shape would bring its own, larger, order budget)
+        s_.close()
+    M._solvers.clear()
+    one = SOS_Aer(max_orders=8)
+    mu = inputs.direction_grid(N)
+    P0a, Pa = inputs.phase_function_device("rayleigh", N, mu, 0.5)
+    P0r, Pr = inputs.phase_function_device("eva", N, mu, 0.5)
+    c = O.make_column(0.5, 120, 25, 17, L, 0.104, 0.120, 1.0, 1.0, 1.0, N, P0a, Pa, P0r, Pr)
+    ref = O.solve_column(c, literal=False, max_orders=8)
+    assert one.n == ref.n == 8 and one.status == _lib.COL_MAXORDERS
+    assert np.array_equal(one.tau, c.tau) and (one.idx_up, one.idx_down) == (c.idx_up, c.idx_down)
+    assert_close(one.I, ref.I, RTOL, "I of the shipped call after 8 orders")
+    assert one.I_saved.shape == (8, L, 2 * N)
+    for k in range(8):
+        assert_close(one.I_saved[k], ref.I_saved[k], RTOL, "order %d of the shipped call" % (k + 1))
 
 
 def test_rccl_entry_points_world_of_one():
