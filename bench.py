@@ -232,10 +232,10 @@ class Lane:
         self.s.solve_device(self.d_tau.data_ptr(), self.d_P0a.data_ptr(), self.d_P0r.data_ptr(), self.I.data_ptr(), tol=1e-4,
                             d_n_orders=self.n.data_ptr(), d_status=self.st.data_ptr())
 
-    def check(self, O, cols):
+    def check(self, O, cols, max_orders=10000):
         """Columns `cols` of the field the last step left on the device against the oracle (vectorised mode, same arithmetic as
         the reference to rounding) on IDENTICAL inputs: the device-built P0 rows go into the oracle; they are compared with the
-        oracle's own evaluation beside that."""
+        oracle's own evaluation beside that.  `max_orders`: the order budget the lane was made with, where it matters."""
         w, N = self.w, self.N
         n_host = self.n.cpu().numpy()
         worst, same_n, p0_err = 0.0, True, 0.0
@@ -243,7 +243,7 @@ class Lane:
             P0a_d, P0r_d = self.d_P0a[b].cpu().numpy(), self.d_P0r[b].cpu().numpy()
             P0a, P0r = oracle_p0(O, w, b)
             p0_err = max(p0_err, float(np.max(np.abs(P0a_d - P0a) / P0a)), float(np.max(np.abs(P0r_d - P0r) / P0r)))
-            ref = O.solve_column(oracle_column(O, w, b, P0a_d, P0r_d), literal=False)
+            ref = O.solve_column(oracle_column(O, w, b, P0a_d, P0r_d), literal=False, max_orders=max_orders)
             got = self.I[b].cpu().numpy()
             scale = np.max(np.abs(ref.I))
             sig = np.abs(ref.I) > 1e-9 * scale
@@ -257,7 +257,8 @@ class Lane:
         self.s.close()
 
 
-def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, max_orders=256, sweep=None):
+def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, max_orders=256, sweep=None, rho=0.15, tau_atm=0.124,
+               check_orders=None):
     """One more configuration of BASELINE.json beside the headline, outside its timed region: `steps` solves one at a time on
     one stream, wall time, its own check.  `sweep`: a prepared sweep (build_sweep / take) instead of n_columns."""
     import torch
@@ -268,11 +269,11 @@ def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, 
         taer = 0.120 if aerosol != "wildfire" else 0.0075
         mu = inputs.direction_grid(N)
         iu, idn = inputs.slab_indices(120, sc["z"][0], sc["z"][1], L)
-        w = dict(B=1, L=L, N=N, mu=mu, tau=inputs.tau_profile(0.124, taer, 120, sc["z"][0], sc["z"][1], L)[None],
+        w = dict(B=1, L=L, N=N, mu=mu, tau=inputs.tau_profile(tau_atm, taer, 120, sc["z"][0], sc["z"][1], L)[None],
                  P_atm=inputs.phase_function_device("rayleigh", N, mu, 0.5, device=local_rank)[1],
                  P_aer=inputs.phase_function_device(aerosol, N, mu, 0.5, 0.7, device=local_rank)[1],
-                 mu0=np.array([0.5]), taer=np.array([taer]), rho=np.array([0.15]), aerosol=aerosol, idx_up=iu, idx_down=idn,
-                 z=sc["z"], tau_atm=0.124, alb_aer=sc["alb_aer"])
+                 mu0=np.array([0.5]), taer=np.array([taer]), rho=np.array([float(rho)]), aerosol=aerosol, idx_up=iu, idx_down=idn,
+                 z=sc["z"], tau_atm=tau_atm, alb_aer=sc["alb_aer"])
     ln = Lane(w, dev, local_rank, max_orders)
     try:
         ln.solve(); torch.cuda.synchronize(dev)                # warm-up
@@ -296,7 +297,17 @@ def extra_case(O, dev, local_rank, n_columns, L, N, aerosol, steps, check_cols, 
         t_byte = 8.0 * L * D * (4 * orders + 2 * w["B"]) / (HBM_PEAK_GBS * 1e9)
         out["roofline_frac_full_product"] = max(t_flop, t_byte) / dt
         out["roofline_frac_executed"] = max(t_flop / 2, t_byte) / dt
-        if check_cols:
+        if check_cols and check_orders:
+            # a size at which the oracle takes seconds per order: the check is of the first `check_orders` orders -- a second
+            # lane with that order budget against the oracle with the same budget
+            lc = Lane(w, dev, local_rank, check_orders, ln.shared())
+            try:
+                lc.solve(); torch.cuda.synchronize(dev)
+                out["check"] = dict(lc.check(O, check_cols, max_orders=check_orders), columns=[int(b) for b in check_cols],
+                                    orders_checked=check_orders)
+            finally:
+                lc.close()
+        elif check_cols:
             out["check"] = dict(ln.check(O, check_cols), columns=[int(b) for b in check_cols])
         return out
     finally:
@@ -691,7 +702,7 @@ def main():
                        "max_order": int(n_host.max()),
                        "not_converged": int((st_host != 0).sum()), "inflight_solves": max(1, a.inflight),
                        "p0": "built on the device (sosrt_phase_p0_dev), outside the timed region",
-                       "library_default": bool(a.groups == "auto" or B <= 256),
+                       "library_default": bool(a.groups == "auto" or B <= 48),
                        "order_loop": {"1": "one column group, one stream (SOSRT_GROUPS=1): no kernel runs beside another; the library "
                                            "alone takes two groups at this size: `two_groups` is what a default library call executes",
                                       "2": "two column groups on two streams (SOSRT_GROUPS=2)",
@@ -797,6 +808,9 @@ def main():
                                                       "efficiency": 512 / (c4s["ms_per_solve"] * 1e-3) / value / 8,
                                                       "note": "512 columns / the slowest shard's solve, gather not included; NOT a measurement of 8 GPUs"}
                 ex["c4_shard"] = c4s
+                # the reference's shipped size and literals (spec:23-96: L = 800, N = 501, grd_alb = 1, tau*_atm = 0.104, EVA aerosol): one
+                # column; the transport is the WIDE instantiation of the chunk-parallel kernel, eight workgroups per column
+                ex["shipped"] = extra_case(O, dev, local_rank, 1, 800, 501, "eva", 5, [0], rho=1.0, tau_atm=0.104, check_orders=6)
                 if a.aerosol != "hg":                    # rounds 1-2 measured the HG(0.7) stand-in: the same sweep shape, for continuity
                     ex["c4_hg"] = extra_case(O, dev, local_rank, 512, 200, 128, "hg", 5, [0])
                     ex["c4_hg"]["order_loop"] = "the library's choice (two column groups)"

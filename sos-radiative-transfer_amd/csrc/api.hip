@@ -66,7 +66,9 @@ struct sosrt_handle {
     static constexpr int kMaxGroups = 2;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int ngroups = 1, want_groups = 0, split_min = 256;      // want_groups 0: two groups above split_min columns (set_columns)
+    // (round 4, alternating runs on one box, shards of the EVA sweep: 32 columns 1.54 -> 1.48 ms, 64 columns 1.71 -> 1.66, 128 columns
+    // 2.06 -> 1.96, 256 columns 2.98 -> 2.82 -- round 3 had only measured 256 and up with the capped contraction; tools/ab_small_groups.py)
+    int ngroups = 1, want_groups = 0, split_min = 48;       // want_groups 0: two groups above split_min columns (set_columns)
     int split_at = -1;                   // SOSRT_GROUP_SPLIT: first column of the second group (default: the middle)
     int prio2 = 0;                       // SOSRT_GROUP_PRIO: the internal stream is created with the highest priority
     // Round 2 capped the contraction at two workgroups per CU with LDS padding (27 008 bytes: 27 656 static + this > 1/3 of 160 KiB)
@@ -482,7 +484,11 @@ LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderIn
         const int cols_now = pl.tail_cols > 0 ? pl.tail_cols : in.nb;
         // chunk-parallel kernel: a column on ceil(N / 64) CUs (two at N = 128, four at N = 256) while that many workgroups per
         // live column fit the device at once (the reflection must stay inside a part)
-        const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= h->cu_count &&
+        // (where the shape has no ring kernel -- odd N, N > 256: the split form's WIDE instantiation -- the alternative is the
+        // register-streaming kernel, one workgroup per column and 650 us per order at the shipped size against 133 for a round of
+        // split workgroups: up to four rounds of them are the faster way)
+        const int split_cap = sh.ring_mode == 3 ? h->cu_count : 4 * h->cu_count;
+        const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= split_cap &&
                                (in.surface == SOSRT_SURFACE_SPECULAR || in.surface == SOSRT_SURFACE_NONE);
         const bool want_scan = h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols);
         const bool scan = want_scan && ((sh.ring_mode == 3 && h->scan_ok && transport_scan_fits(g, sh.nzcap, false)) ||
@@ -918,7 +924,7 @@ static int set_columns_impl(sosrt_handle* h, int B, int geometry, int surface, c
     std::vector<int> slab, plain, iup(B, 0), idn(B, 0);
     auto zone_end = [&](int b, int z) { return z + 1 < nz[b] ? zr0[b * kMaxZones + z + 1] - 1 : L - 1; };
     // column groups of the order loop: two contiguous halves for a large batch
-    // (auto: two groups for a batch of more than SPLIT_MIN = 256 columns.  Round 3, EVA / wildfire sweeps with one and two groups
+    // (auto: two groups for a batch of more than SPLIT_MIN columns (48; 256 in round 3).  Round 3, EVA / wildfire sweeps with one and two groups
     // alternating on one box: 288 x (200, 128) 3.65 -> 3.33 ms, 320 x 3.89 -> 3.50, 512 x 5.03 -> 4.75, 1024 x 9.2 -> 8.15,
     // 2048 x 16.6 -> 15.5, 4096 x 32.4 -> 30.3; 512 x (200, 64) 3.02 -> 2.94, 1024 x (200, 64) 5.10 -> 4.69; 512 x (200, 256)
     // 13.1 -> 12.65, 512 x (400, 256) 13.5 -> 12.8, 4096 x (400, 256) 106 -> 103.7; 256 x (200, 128) unchanged.  The gain is the

@@ -165,11 +165,12 @@ def test_large_ragged_batch_of_small_columns():
         assert_close(r.I[b], ref.I, RTOL, "column %d" % b)
 
 
-def test_c5_full_size_batch_on_device():
-    """BASELINE's largest configuration at full size -- 4096 columns, L = 400, N = 256 (33 GB of fields on
-    the device) -- through the device-pointer entry point: every column converges, the run is
-    deterministic, order counts are monotone along the sweep axes, and one sampled column matches the
-    oracle."""
+def test_c5_sized_batch_of_the_hg_stand_in_on_device():
+    """A batch of the SIZE of BASELINE's largest configuration -- 4096 columns, L = 400, N = 256 (33 GB of fields on the
+    device) -- with the HG(0.7) stand-in on the EVA slab (the wildfire scenario itself: 64 of its columns against the oracle in
+    tests/test_gpu_mie.py, the whole 4096-column sweep with a sampled column in bench.py's `extras.c5`), through the
+    device-pointer entry point: every column converges, the run is deterministic, order counts are monotone along the sweep
+    axes, and one sampled column matches the oracle."""
     import os
     import sys
     import torch

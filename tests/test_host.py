@@ -210,29 +210,38 @@ def test_launch_plan_of_the_order_loop():
     assert (plan(128, 200, 1, 1)["order_loop"], plan(128, 200, 1, 1)["ol_parts"], plan(128, 200, 1, 1)["ol_grid"]) == (1, 2, 256)
     p = plan(256, 200, 1, 1)
     assert (p["transport"], p["parts"], p["order_loop"], p["ol_parts"]) == (T.PLAN_TRANSPORT_SCAN, 4, 1, 4)
-    assert plan(256, 200, 64, 64)["order_loop"] == 0 and plan(256, 200, 64, 32)["order_loop"] == 1     # 4 x 64 > 128 >= 4 x 32
-    # the 64-column shard of the C4 sweep on one of 8 GPUs: in the launch from the second order on
-    p = plan(128, 200, 64, 64)
+    assert plan(256, 200, 40, 40)["order_loop"] == 0 and plan(256, 200, 40, 32)["order_loop"] == 1     # 4 x 40 > 128 >= 4 x 32
+    # a batch of up to 48 columns is one column group; the 64-column shard of the C4 sweep on one of 8 GPUs is two groups of 32
+    p = plan(128, 200, 40, 40)
     assert (p["groups"], p["order_loop"], p["ol_parts"], p["ol_grid"]) == (1, 1, 2, 256)
-    assert plan(128, 200, 200, 129)["order_loop"] == 0 and plan(128, 200, 200, 128)["order_loop"] == 1   # one workgroup per column
+    p = plan(128, 200, 64, 32)
+    assert (p["groups"], p["order_loop"], p["ol_parts"], p["ol_grid"]) == (2, 1, 2, 128)
+    assert plan(128, 200, 200, 65)["order_loop"] == 0 and plan(128, 200, 200, 64)["ol_parts"] == 1      # one workgroup per column
     # a Lambertian surface couples all directions at the ground: one workgroup per column, in both kernels
-    p = plan(128, 200, 64, 40, surface="lambertian")
+    p = plan(128, 200, 40, 40, surface="lambertian")
     assert (p["transport"], p["parts"], p["order_loop"], p["ol_parts"]) == (T.PLAN_TRANSPORT_SCAN, 1, 1, 1)
     p = plan(256, 200, 8, 8, surface="lambertian")  # ... which N = 256 does not have: ring kernel, no order-loop launch
     assert (p["transport"], p["order_loop"]) == (T.PLAN_TRANSPORT_RING, 0)
     # N <= 64: one lane group, one workgroup per column
     p = plan(32, 50, 1, 1)
     assert (p["transport"], p["parts"], p["order_loop"], p["ol_parts"]) == (T.PLAN_TRANSPORT_SCAN, 1, 1, 1)
-    # the reference's shipped size (odd N, N > 256): the register-streaming kernel + repair pass; N = 70: the general kernel
+    # the reference's shipped size (odd N, N > 256, 100 chunks per sweep): the chunk-parallel kernel's WIDE instantiation, eight
+    # workgroups per column, for up to four rounds of them; beyond that the register-streaming kernel + repair pass; a Lambertian
+    # surface (no split form) takes that one too; N = 70: the general kernel
     p = plan(501, 800, 1, 1)
-    assert (p["transport"], p["repair"], p["order_loop"]) == (T.PLAN_TRANSPORT_FAST, 1, 0)
+    assert (p["transport"], p["parts"], p["repair"], p["order_loop"]) == (T.PLAN_TRANSPORT_SCAN, 8, 0, 0)
+    assert (plan(501, 800, 128, 128)["transport"], plan(501, 800, 128, 128)["parts"]) == (T.PLAN_TRANSPORT_SCAN, 8)
+    p = plan(501, 800, 400, 150)                    # two groups of 200, 150 live: 8 x 150 workgroups are more than four rounds
+    assert (p["transport"], p["repair"]) == (T.PLAN_TRANSPORT_FAST, 1)
+    assert plan(501, 800, 1, 1, surface="lambertian")["transport"] == T.PLAN_TRANSPORT_FAST
+    assert (plan(300, 96, 2, 2)["transport"], plan(300, 96, 2, 2)["parts"]) == (T.PLAN_TRANSPORT_SCAN, 5)
     assert plan(70, 50, 4, 4)["transport"] == T.PLAN_TRANSPORT_GENERAL
     # columns of more than three zones (two aerosol layers): ring-class kernels, dense contraction, no order-loop launch
-    p = plan(128, 200, 64, 20, zones=5)
+    p = plan(128, 200, 40, 20, zones=5)
     assert (p["gemm"], p["transport"], p["order_loop"]) == (G.PLAN_GEMM_DENSE, T.PLAN_TRANSPORT_SCAN, 0)
     # a smaller device: the launch is sized by its CUs
     p = plan(128, 200, 16, 16, cus=64)
     assert (p["order_loop"], p["ol_parts"], p["ol_grid"]) == (1, 2, 64)
-    assert plan(128, 200, 64, 64, cus=64)["order_loop"] == 0
+    assert plan(128, 200, 40, 40, cus=64)["order_loop"] == 0
     with pytest.raises(ValueError):
         plan(128, 200, 4, 5)
