@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def family(name):
-    for k in ("k_jn_gemm", "k_transport_ring", "k_transport_scan", "k_transport_fast", "k_transport", "k_first_order", "k_attenuation", "k_smallmu", "k_epilogue",
+    for k in ("k_order_loop", "k_jn_gemm", "k_transport_ring", "k_transport_scan", "k_transport_fast", "k_transport", "k_first_order", "k_attenuation", "k_smallmu", "k_epilogue",
               "k_phase_p0", "k_prepare", "k_tau_hash", "k_tau_rep", "k_wmix", "k_finalize"):
         if k in name:
             return k
@@ -30,7 +30,8 @@ def collect(path, counter):
 
 def sha():
     h = hashlib.sha256()
-    for name in ("jn_gemm.hip", "transport_ring.hip", "transport_scan.hip", "kernels.hpp", "transport_util.hpp"):
+    for name in ("jn_gemm.hip", "jn_gemm_tile.hpp", "transport_ring.hip", "transport_scan.hip", "transport_scan_body.hpp", "order_loop.hip",
+                 "kernels.hpp", "transport_util.hpp"):                      # (= bench.py: kernel_sources_sha)
         h.update(open(os.path.join(ROOT, "sos-radiative-transfer_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
