@@ -174,6 +174,7 @@ struct sosrt_handle {
     double ol_frac = 0.5;                // ... while the transport workgroups of the live columns are at most this share of the grid
     int* d_olsync = nullptr;             // [kMaxGroups][order_loop_sync_ints(kOrderLoopMaxCols)] words of a launch
     int* h_oldone = nullptr;             // pinned [kMaxGroups][2]: {state, tag} reported by the launch's last workgroup
+    unsigned long long* d_ollog = nullptr;   // diagnostic builds (-DSOSRT_OL_STAMPS): event log of an order-loop launch
     int ol_launches = 0, ol_refused = 0; // launches of the last solve; launches that found their grid not resident
     bool ol_group_used[kMaxGroups] = {false, false};      // column groups of the last solve that ran (to the end) in an order-loop launch
     // RCCL communicator of the sharded solve (sosrt_comm_init)
@@ -689,7 +690,7 @@ int sosrt_destroy(sosrt_t* h) {
                         h->d_idx_down, h->d_scal, h->d_desc, h->d_rca, h->d_rcr, h->d_slabrows, h->d_mainrows, h->d_tau, h->d_P0a,
                         h->d_P0r, h->d_Jn, h->d_InA, h->d_InB, h->d_I, h->d_E, h->d_active, h->d_norders, h->d_status,
                         h->d_nactive_sets, h->d_ratio, h->d_redo, h->d_erep, h->d_tauhash, h->d_Wmix, h->d_mixca, h->d_mixcr,
-                        h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_scan_scratch, h->d_scan_sync, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr, h->d_olsync};
+                        h->d_mixgroup, h->d_Wa_s, h->d_Wr_s, h->d_Wmix_s, h->d_scan_scratch, h->d_scan_sync, h->d_w, h->d_phi, h->d_z, h->d_tab, h->d_slabtilegroup, h->d_livelist, h->d_Wa32, h->d_Wmix32, h->d_nz, h->d_zr0, h->d_zmix, h->d_zwr, h->d_zdtr, h->d_olsync, h->d_ollog};
         for (void* p : ptrs)
             if (p) hipFree(p);
         if (h->h_pub) hipHostFree(h->h_pub);
@@ -1381,6 +1382,19 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 ol_release(h->device, ol_held[k]);
                 ol_held[k] = 0;
                 progressed = true;
+#ifdef SOSRT_OL_STAMPS
+                if (h->d_ollog && getenv("SOSRT_OL_LOG")) {
+                    std::vector<unsigned long long> lg(65001);
+                    (void)hipStreamSynchronize(group_stream(h, k));
+                    (void)hipMemcpy(lg.data(), h->d_ollog, lg.size() * 8, hipMemcpyDeviceToHost);
+                    if (FILE* f = fopen(getenv("SOSRT_OL_LOG"), "a")) {
+                        fprintf(f, "# launch columns<=%d order0=%d events=%llu\n", q.known, q.n + 1, lg[0]);
+                        for (unsigned long long i = 0; i < lg[0] && i < 65000; ++i)
+                            fprintf(f, "%llu %llu %llu %llu\n", lg[1 + i] >> 48, (lg[1 + i] >> 40) & 0xff, (lg[1 + i] >> 32) & 0xff, lg[1 + i] & 0xffffffffull);
+                        fclose(f);
+                    }
+                }
+#endif
                 if (state == kOlReady) { q.done = true; --live_groups; h->ol_group_used[k] = true; continue; }
                 if (state == kOlAborted) {
                     // never expected: say where the launch stood (the words of the launch, first columns)
@@ -1461,6 +1475,13 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 oa.sync = h->d_olsync + (size_t)k * order_loop_sync_ints(kOrderLoopMaxCols);
                 oa.host_done = h->h_oldone + 2 * k;
                 oa.tag = q.ol_tag = ((++h->pub_seq) & 0x3fffffff) | 0x40000000;
+#ifdef SOSRT_OL_STAMPS   // diagnostic builds: SOSRT_OL_LOG=<file> receives the launch's event log (tools/ol_timeline.py)
+                if (getenv("SOSRT_OL_LOG")) {
+                    if (!h->d_ollog) { if (int e = dalloc(&h->d_ollog, 65001)) return bail(e); }
+                    HIPCHK(hipMemsetAsync(h->d_ollog, 0, 8, sg));
+                    oa.log = h->d_ollog;
+                }
+#endif
                 prof_break(h);
                 HIPCHK(hipMemsetAsync(oa.sync, 0, order_loop_sync_ints(q.known) * sizeof(int), sg));
                 prof_begin(h, SOSRT_K_ORDER_LOOP, k);

@@ -6,9 +6,13 @@
 // results of lane l are D[i = 4r + (l>>4)][j = l&15], r = 0..3.
 //
 // Workgroup tile: 64 rows x 128 columns, 4 waves, each wave 4x2 MFMA tiles (64 accumulator
-// registers).  Operands are staged through LDS in k-chunks of GEMM_KC = 16 with row strides chosen so
-// that the fragment reads (ds_read_b64) are bank-conflict free: A rows 18 doubles, W rows 144 doubles
-// (288 = 32 mod 64 dwords).  The global loads of the next chunk are in registers while the current one
+// registers).  Operands are staged through LDS in k-chunks of GEMM_KC = 16 with row strides chosen for
+// the fragment READS (ds_read_b64: A rows 18 doubles, W rows 144 doubles = 32 mod 64 dwords, so the 32
+// lanes of a half wave fall into 64 distinct banks).  The kernel is not free of bank conflicts, though:
+// the staging STORES are 16 bytes per lane, four lanes per 18-double row, and SQ_LDS_BANK_CONFLICT counts
+// 8.9e6 cycles per launch of the symmetric form, 18 % of the launch's CU-cycles, against an MFMA pipe
+// busy for 47 % of the SIMD-cycles (profiles/r04_pmc_gemm_sq.txt; round 2's "conflict free" was the reads).
+// The global loads of the next chunk are in registers while the current one
 // is multiplied (one chunk ahead in the dense tilings, four workgroups per CU hide the rest; two chunks
 // ahead in two register sets, loop unrolled by two, in the tail tiling, where a workgroup is alone on
 // its CU).

@@ -44,9 +44,16 @@ struct ColumnRows {             // the plain or the slab rows of one column
 // workgroups): the rows of In_1 were stored write-through by workgroups of this launch and are loaded `sc1` (past this CU's L1,
 // bload_aux), the rows of Jn are stored write-through for the transport's loaders; both through buffer descriptors of the
 // tile's column (RowOf = ColumnRows).  The arithmetic is the same.
-template <int RT, bool SLAB, bool DEEP = false, bool SYM = false, class RowOf = ListRows, bool COH = false>
+//
+// ASTAGE (with COH, DEEP): the tile's rows of In_1 are brought into LDS WHOLE, at once, by LDS-DMA (`sRaw`: 16 RT rows of D + 2
+// doubles), and the k-loop takes its A operand from there.  A workgroup of the order-loop launch is alone on its CU and its A
+// rows come from memory (they were stored write-through moments ago): staged two k-chunks ahead in registers, every pair of
+// chunks waited for a memory round trip of its own -- 12.5 us per tile of 8 chunks, measured -- where one round trip serves.
+template <int RT, bool SLAB, bool DEEP = false, bool SYM = false, class RowOf = ListRows, bool COH = false, bool ASTAGE = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double* sB, int* s_any, int tile, int bn0,
-                                          RowOf row_of, bool check_active, const double* __restrict__ wmix = nullptr) {
+                                          RowOf row_of, bool check_active, const double* __restrict__ wmix = nullptr,
+                                          double* sRaw = nullptr) {
+    static_assert(!ASTAGE || (COH && DEEP), "ASTAGE is a form of the order-loop launch's tile");
     constexpr int BM = 16 * RT;
     double* const sAv = sA + BM * A_LD;          // SYM: the v operand next to the u operand
     const int Nn = g.D >> 1, Nh = g.Wld >> 1;
@@ -84,7 +91,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A + (size_t)colrow0 * D, colbytes);
     const __amdgpu_buffer_rsrc_t rC = make_rsrc(g.C + (size_t)colrow0 * D, colbytes);
     const int avo = ((grow >= 0 ? grow : colrow0) - colrow0) * D * 8;
-#define SOSRT_A2(off_) (COH ? bload2_aux<16>(rA, avo + (off_) * 8, 0) : *reinterpret_cast<const double2*>(Arow + (off_)))
+    const int RS = D + 2;                                       // ASTAGE: row stride of sRaw (16-byte aligned rows, 4 banks apart)
+    if constexpr (ASTAGE) {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t_;
+        __syncthreads();                                        // (s_rowid is complete; the previous tile has left sRaw)
+        const int rowbytes = D * 8, pieces = (rowbytes + 1023) / 1024;
+        for (int r = wave; r < BM; r += 4) {
+            const int gr_ = s_rowid[r];
+            if (gr_ < 0) continue;                              // (uniform) padding row: its coefficient is zero and its reads are guarded
+            const int ro = (gr_ - colrow0) * rowbytes;
+            for (int pc = 0; pc < pieces; ++pc)
+                if (pc * 1024 + lane * 16 < rowbytes)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t_)(sRaw + (size_t)r * RS + pc * 128), 16, lane * 16, ro + pc * 1024, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#define SOSRT_A2(off_) (ASTAGE ? *reinterpret_cast<const double2*>(sRaw + (size_t)arow * RS + (off_)) \
+                               : (COH ? bload2_aux<16>(rA, avo + (off_) * 8, 0) : *reinterpret_cast<const double2*>(Arow + (off_))))
 
     f64x4 acc[RT][2];
 #pragma unroll

@@ -231,6 +231,8 @@ struct OrderLoopArgs {
     int* sync;                 // order_loop_sync_ints(cap) zeroed ints
     int* host_done;            // pinned {status, tag}
     int tag;
+    unsigned long long* log = nullptr;   // diagnostic builds (-DSOSRT_OL_STAMPS): [1 + 65000] event log, log[0] = count
+    int astage = 0;            // (set by the launcher) the contraction role stages its tiles' rows of In_1 whole in LDS
 };
 bool order_loop_ok(const Grid& g, bool split);
 int order_loop_parts(const Grid& g, bool split);

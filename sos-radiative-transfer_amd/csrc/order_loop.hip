@@ -127,6 +127,7 @@ __global__ __launch_bounds__(768) void k_order_loop(OrderLoopArgs p) {
             const int T = tiles_of(p.col0 + b);
             ScanFused fu;
             fu.jn_done = cs + kOlJnDone; fu.ord_done = cs + kOlOrdDone; fu.col_stop = cs + kOlColStop; fu.abort = abort; fu.orders = sy + kOlOrders;
+            fu.log = p.log; fu.wg = wg;
             for (int k = 1; k <= p.kmax; ++k) {
                 // An order's body is the one-order kernel's, and is to be compiled like it: nothing of it hoisted out of this
                 // loop (per-lane constants, descriptors and table addresses kept live across the whole body cost the sweeps
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(768) void k_order_loop(OrderLoopArgs p) {
                 a.order = p.order0 + k - 1;
                 fu.k = k; fu.first = k == 1; fu.last = k == p.kmax; fu.jn_need = k * T;
                 __syncthreads();                       // (the end of the previous order has read what this one's head resets)
+                if (tid == 0) SOSRT_OL_STAMP(p.log, wg, k, 1);
                 if (transport_scan_order<true, false, SPLIT, NC, false, true>(a, p.fixcap, bb, part, fu)) break;
             }
         } else if (SOSRT_OL_ONLY != 1) {
@@ -148,6 +150,8 @@ __global__ __launch_bounds__(768) void k_order_loop(OrderLoopArgs p) {
             extern __shared__ double sm[];
             double* sA = sm;
             double* sB = sm + 2 * 16 * TAIL_RT * A_LD;
+            double* sRaw = sB + GEMM_KC * B_LD;          // [16 TAIL_RT][D + 2]: the tile's rows of In_1, whole (jn_gemm_tile.hpp, ASTAGE)
+            const bool astage = p.astage != 0;           // (they fit the launch's LDS: N <= 128 beside the transport role's need)
             const int NW = G - NT, w = wg - NT;
             const int TPC = (ts + tm) * nct;           // schedule slots per column (a column with fewer rows leaves some empty)
             GemmArgs gk = p.gm;
@@ -191,22 +195,28 @@ __global__ __launch_bounds__(768) void k_order_loop(OrderLoopArgs p) {
                             __builtin_amdgcn_s_sleep(8);
                         }
                         s_misc[2] = go;
+                        SOSRT_OL_STAMP(p.log, wg, k, 10);                                   // tile's rows ready (or column stopped)
                     }
                     __syncthreads();
                     if (!s_misc[2]) continue;
                     if (tt < ts) {
-                        if (p.gm.Wmix)
-                            gemm_tile<TAIL_RT_SLAB, false, kOlDeep, true, ColumnRows, true>(gk, sA, sB, nullptr, tt, bn0, ColumnRows{bg * L, iu, ns, ns, true},
-                                                                                         false, p.gm.Wmix + (size_t)p.gm.mix_group[bg] * p.gm.Dp * p.gm.Wld);
-                        else
-                            gemm_tile<TAIL_RT_SLAB, true, kOlDeep, true, ColumnRows, true>(gk, sA, sB, nullptr, tt, bn0, ColumnRows{bg * L, iu, ns, ns, true}, false);
+                        const ColumnRows cr{bg * L, iu, ns, ns, true};
+                        const double* wm = p.gm.Wmix ? p.gm.Wmix + (size_t)p.gm.mix_group[bg] * p.gm.Dp * p.gm.Wld : nullptr;
+                        if (wm && astage) gemm_tile<TAIL_RT_SLAB, false, true, true, ColumnRows, true, true>(gk, sA, sB, nullptr, tt, bn0, cr, false, wm, sRaw);
+                        else if (wm) gemm_tile<TAIL_RT_SLAB, false, kOlDeep, true, ColumnRows, true>(gk, sA, sB, nullptr, tt, bn0, cr, false, wm);
+                        else gemm_tile<TAIL_RT_SLAB, true, kOlDeep, true, ColumnRows, true>(gk, sA, sB, nullptr, tt, bn0, cr, false);
                     } else {
-                        gemm_tile<TAIL_RT, false, kOlDeep, true, ColumnRows, true>(gk, sA, sB, nullptr, tt - ts, bn0, ColumnRows{bg * L, iu, ns, L - ns, false}, false);
+                        const ColumnRows cr{bg * L, iu, ns, L - ns, false};
+                        if (astage) gemm_tile<TAIL_RT, false, true, true, ColumnRows, true, true>(gk, sA, sB, nullptr, tt - ts, bn0, cr, false, nullptr, sRaw);
+                        else gemm_tile<TAIL_RT, false, kOlDeep, true, ColumnRows, true>(gk, sA, sB, nullptr, tt - ts, bn0, cr, false);
                     }
                     // the tile's rows (write-through) acknowledged by every wave, then one lane counts it
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_fetch_add(cs + kOlJnDone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) {
+                        __hip_atomic_fetch_add(cs + kOlJnDone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        SOSRT_OL_STAMP(p.log, wg, k, 11);                                   // tile stored and counted
+                    }
                 }
             }
         }
@@ -230,6 +240,7 @@ unsigned order_loop_block(const Grid& g) {
     return (unsigned)((nwc * ScanCfg<SPLIT>::SW + NLOAD) * 64);
 }
 size_t order_loop_gemm_lds() { return (size_t)(2 * 16 * TAIL_RT * A_LD + GEMM_KC * B_LD) * sizeof(double); }
+size_t order_loop_raw_lds(const Grid& g) { return (size_t)16 * TAIL_RT * (g.D + 2) * sizeof(double); }
 
 template <bool SPLIT, int NC>
 hipError_t launch_order_loop_t(hipStream_t s, int grid, const OrderLoopArgs& p) {
@@ -242,7 +253,11 @@ hipError_t launch_order_loop_t(hipStream_t s, int grid, const OrderLoopArgs& p) 
     }
     size_t shm = scan_lds_bytes<SPLIT>(p.t.g, kRingZones);
     if (shm < order_loop_gemm_lds()) shm = order_loop_gemm_lds();
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(order_loop_block<SPLIT>(p.t.g)), shm, s, p);
+    OrderLoopArgs q = p;
+    // the contraction role's whole-tile staging of In_1, where it fits the CU's LDS (N <= 128; a launch is one workgroup per CU)
+    q.astage = order_loop_gemm_lds() + order_loop_raw_lds(p.t.g) <= kScanLdsBytes ? 1 : 0;
+    if (q.astage && shm < order_loop_gemm_lds() + order_loop_raw_lds(p.t.g)) shm = order_loop_gemm_lds() + order_loop_raw_lds(p.t.g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(order_loop_block<SPLIT>(p.t.g)), shm, s, q);
     return hipGetLastError();
 }
 

@@ -99,7 +99,21 @@ struct ScanFused {
     int* col_stop = nullptr;         // [1] set (before ord_done) when the column stops
     int* abort = nullptr;            // [1] launch-wide: a bounded poll expired somewhere
     int* orders = nullptr;           // [1] launch-wide: column.orders finished (statistics)
+    unsigned long long* log = nullptr;   // diagnostic builds (-DSOSRT_OL_STAMPS): event log of the launch
+    int wg = 0;
 };
+// diagnostic builds: one 64-bit event {workgroup:16, order:8, event:8, wall clock (10 ns):32} appended to the launch's log
+#ifdef SOSRT_OL_STAMPS
+__device__ __forceinline__ void ol_stamp(unsigned long long* log, int wg, int k, int ev) {
+    if (!log) return;
+    const unsigned long long i = __hip_atomic_fetch_add(log, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i < 65000) log[1 + i] = ((unsigned long long)(wg & 0xffff) << 48) | ((unsigned long long)(k & 0xff) << 40) | ((unsigned long long)(ev & 0xff) << 32) |
+                                (unsigned long long)(wall_clock64() & 0xffffffffull);
+}
+#define SOSRT_OL_STAMP(log_, wg_, k_, ev_) ol_stamp(log_, wg_, k_, ev_)
+#else
+#define SOSRT_OL_STAMP(log_, wg_, k_, ev_)
+#endif
 // bounded poll of a word another workgroup publishes (agent-scope, past the L1); false: gave up, *abort set
 __device__ __forceinline__ bool fused_wait_ge(const int* p, int want, int* abort) {
     for (unsigned it = 0;; ++it) {
@@ -418,6 +432,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
     if (FUSED && loader) {
         // every tile of this order's source function is stored (and acknowledged: order_loop.hip) before its count moves
         if (!fused_wait_ge(fu.jn_done, fu.jn_need, fu.abort) && lane == 0) s_flag[2] = 1;
+        if (FUSED && wid == ncw && lane == 0) SOSRT_OL_STAMP(fu.log, fu.wg, fu.k, 2);      // source function complete
     }
 
     // =============================== downward ===============================
@@ -713,6 +728,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
         }
     }
     stamp(2);
+    if (FUSED && tid == 0) SOSRT_OL_STAMP(fu.log, fu.wg, fu.k, 3);                          // (wave 0) downward sweep done
     __syncthreads();                                            // the surface row is complete
     stamp(3);
 
@@ -954,6 +970,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
         if (w0 && notfound && lane == 0 && N - 3 <= 61) s_flag[1] = 1;     // every candidate was in this lane group: IndexError
     }
     stamp(4);
+    if (FUSED && tid == 0) SOSRT_OL_STAMP(fu.log, fu.wg, fu.k, 4);                          // (wave 0) upward sweep done
     // FUSED: the rows of this order are read by other workgroups as soon as the column's verdict is out: every wave's stores
     // (write-through) are acknowledged before the barrier that the publishing thread passes
     if (FUSED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -972,6 +989,7 @@ __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the rows the end of the order rewrote (finishing, redo)
             __syncthreads();
             if (tid == 0) {
+                SOSRT_OL_STAMP(fu.log, fu.wg, fu.k, 5);                                     // verdict about to be published
                 if (fu.orders) __hip_atomic_fetch_add(fu.orders, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (st) __hip_atomic_store(fu.col_stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
