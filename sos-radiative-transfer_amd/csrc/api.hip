@@ -479,9 +479,7 @@ LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderIn
                            : (pl.tail_cols <= h->gemm_small_cols ? ((use_sym(h) && pl.tail_cols <= 32) ? SOSRT_PLAN_GEMM_LIVE32_DEEP : SOSRT_PLAN_GEMM_LIVE32)
                                                                  : SOSRT_PLAN_GEMM_LIVE64);
     // transport
-    if (!sh.fast) {
-        pl.transport = SOSRT_PLAN_TRANSPORT_GENERAL;
-    } else {
+    {
         const int cols_now = pl.tail_cols > 0 ? pl.tail_cols : in.nb;
         // chunk-parallel kernel: a column on ceil(N / 64) CUs (two at N = 128, four at N = 256) while that many workgroups per
         // live column fit the device at once (the reflection must stay inside a part)
@@ -492,10 +490,13 @@ LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderIn
         const bool can_split = h->scan_split && h->scan_split_ok && transport_scan_parts(g) * cols_now <= split_cap &&
                                (in.surface == SOSRT_SURFACE_SPECULAR || in.surface == SOSRT_SURFACE_NONE);
         const bool want_scan = h->transport_mode == 4 || (h->transport_mode == 3 && cols_now <= h->scan_cols);
-        const bool scan = want_scan && ((sh.ring_mode == 3 && h->scan_ok && transport_scan_fits(g, sh.nzcap, false)) ||
-                                        (can_split && transport_scan_fits(g, sh.nzcap, true)));
-        pl.transport = scan ? SOSRT_PLAN_TRANSPORT_SCAN : (sh.ring_mode == 3 ? SOSRT_PLAN_TRANSPORT_RING : SOSRT_PLAN_TRANSPORT_FAST);
-        if (scan && can_split && transport_scan_fits(g, sh.nzcap, true)) pl.parts = transport_scan_parts(g);
+        // (the split form also takes the shapes no wave-independent kernel does -- the rewritten directions straddle two waves of a
+        // half row, e.g. N = 70, 129, 257: sh.fast is false -- as long as the attenuation tables are built)
+        const bool split = can_split && transport_scan_fits(g, sh.nzcap, true) && (sh.fast || (h->use_etab && h->transport_mode >= 3));
+        const bool scan = want_scan && ((sh.fast && sh.ring_mode == 3 && h->scan_ok && transport_scan_fits(g, sh.nzcap, false)) || split);
+        pl.transport = scan ? SOSRT_PLAN_TRANSPORT_SCAN
+                            : (!sh.fast ? SOSRT_PLAN_TRANSPORT_GENERAL : (sh.ring_mode == 3 ? SOSRT_PLAN_TRANSPORT_RING : SOSRT_PLAN_TRANSPORT_FAST));
+        if (scan && split) pl.parts = transport_scan_parts(g);
         pl.repair = (h->N - 3 > 61 && pl.transport == SOSRT_PLAN_TRANSPORT_FAST) ? 1 : 0;
     }
     // order-loop kernel: the remaining orders in one launch once the live columns' transport workgroups are a small share of the
@@ -867,7 +868,9 @@ int sosrt_set_grid(sosrt_t* h, const double* mu) {
     h->scan_ok = h->ring_ok && transport_scan_ok(h->g);
     // (N in (128, 256]: the chunk-parallel kernel has this form only; it does not need the ring kernel's shape -- odd N, N up to
     // 512 and L up to 1024 take its WIDE instantiation: the reference's shipped N = 501, L = 800)
-    h->scan_split_ok = h->fast_ok && transport_scan_split_ok(h->g);
+    // (nor the condition of the wave-independent kernels that the rewritten mu -> 0- directions and their sources sit in the last
+    // wave of a half row: part 0 of the split form holds the downward directions N-64 .. N-1 in ONE wave whatever N is)
+    h->scan_split_ok = transport_scan_split_ok(h->g);
     return 0;
 }
 
@@ -1505,7 +1508,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             }
             prof_begin(h, SOSRT_K_TRANSPORT, k);
             double* sv_n = (d_I_saved_out && n <= h->saved_slots) ? d_I_saved_out + (size_t)q.b0 * saved_stride + (size_t)(n - 1) * LD : nullptr;
-            if (fast) {
+            if (pl.transport != SOSRT_PLAN_TRANSPORT_GENERAL) {
                 // once the device has reported that no |mu| < 0.01 lane keeps its k_smallmu value, the ring kernel
                 // need not stage those rows either
                 Grid gt = g;

@@ -33,6 +33,16 @@ namespace sosrt {
 
 namespace {
 
+// MFMA row tiles of a slab-row workgroup of the dense tiling: the slab rows are the last workgroups of a launch, and the last
+// (partial) round of workgroups costs a whole tile's time whatever its fill -- with 16-row slab tiles (1) instead of 32-row ones (2)
+// that round is twice as full and half as long.  (A row's arithmetic does not depend on its tile's height: the live-column tilings
+// have always used 16-row slab tiles.)
+#ifndef SOSRT_DENSE_SLAB_RT
+#define SOSRT_DENSE_SLAB_RT 1
+#endif
+constexpr int DENSE_SLAB_RT = SOSRT_DENSE_SLAB_RT;
+constexpr int DENSE_SLAB_ROWS = 16 * DENSE_SLAB_RT;
+
 template <bool SYM>
 __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     publish_live(g);
@@ -43,7 +53,7 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
     // tile read the same rows of In_1: numbering them 8 apart puts them on one XCD, a few dispatches apart,
     // so that In_1 comes from HBM once instead of once per column tile.
     const int tiles_main = (g.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT);
-    const int tiles = tiles_main + (g.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);
+    const int tiles = tiles_main + (g.n_slab + DENSE_SLAB_ROWS - 1) / DENSE_SLAB_ROWS;
     const int nct = (g.D + GEMM_BN - 1) / GEMM_BN;
     const int id = blockIdx.x;
     const int tile = (id / (8 * nct)) * 8 + (id & 7), bn0 = ((id >> 3) % nct) * GEMM_BN;
@@ -55,10 +65,11 @@ __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
         // group's combined matrix, the same arithmetic as the live-column tilings (a column's result does not
         // depend on which tiling, or which batch, it was computed in)
         const int st = tile - tiles_main;
-        gemm_tile<2, false, false, SYM>(g, sA, sB, &s_any, st, bn0, ListRows{g.rows_slab, g.n_slab}, true,
-                                        g.Wmix + (size_t)g.slab_tile_group[st] * g.Dp * g.Wld);
+        // (the host lists a group for every 32 slab rows)
+        gemm_tile<DENSE_SLAB_RT, false, false, SYM>(g, sA, sB, &s_any, st, bn0, ListRows{g.rows_slab, g.n_slab}, true,
+                                                    g.Wmix + (size_t)g.slab_tile_group[st * DENSE_SLAB_ROWS / 32] * g.Dp * g.Wld);
     } else {
-        gemm_tile<2, true, false, SYM>(g, sA, sB, &s_any, tile - tiles_main, bn0, ListRows{g.rows_slab, g.n_slab}, true);
+        gemm_tile<DENSE_SLAB_RT, true, false, SYM>(g, sA, sB, &s_any, tile - tiles_main, bn0, ListRows{g.rows_slab, g.n_slab}, true);
     }
 }
 
@@ -182,7 +193,7 @@ void launch_wmix(hipStream_t s, size_t n, int ngroups, const double* Wa, const d
 }
 
 void launch_gemm(hipStream_t s, const GemmArgs& a) {
-    const int tiles = (a.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT) + (a.n_slab + GEMM_BM / 2 - 1) / (GEMM_BM / 2);
+    const int tiles = (a.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT) + (a.n_slab + DENSE_SLAB_ROWS - 1) / DENSE_SLAB_ROWS;
     if (tiles <= 0) return;
     const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
     dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nct));

@@ -26,7 +26,7 @@ def _oracle(mu0, taer, rho, L, N, P_atm, P_aer, z_up, z_down, alb_aer, surface="
     (200, 256, (25, 17), [(0.5, 0.12, 0.15)]),                                   # C3: EVA-like column, D = 512
     (400, 256, (15, 14), [(0.5, 0.0075, 0.15), (0.3, 0.05, 0.6)]),               # C5: wildfire slab (thin), L = 400
     (64, 48, (30, 10), [(0.7, 0.3, 0.2), (0.25, 1.0, 0.0)]),                     # 48 directions: one partly filled wave
-    (50, 70, (40, 20), [(0.6, 0.2, 0.1), (0.9, 0.5, 0.2)]),                      # 70: extrapolation straddles two waves -> general kernel
+    (50, 70, (40, 20), [(0.6, 0.2, 0.1), (0.9, 0.5, 0.2)]),                      # 70: extrapolation straddles two waves of a half row: split chunk-parallel kernel (part 0 holds them in one)
     (90, 192, (25, 17), [(0.4, 0.12, 0.3)]),                                     # three waves per sweep
     (600, 32, (25, 17), [(0.5, 0.12, 0.15)]),                                    # more than 64 chunks per sweep: every chunk takes the ring kernel's general body
     (520, 64, (60, 30), [(0.6, 0.3, 0.2)]),                                      # 65 chunks, zone boundaries far down
@@ -488,8 +488,20 @@ def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
     a, b = out["ring"], out["scan"]
     assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status)
     live = a.status == 0
+    # where the ring kernel takes the shape the two share their arithmetic: the same bits.  N = 200: the rewritten mu -> 0-
+    # directions straddle two waves of a half row, "ring" falls to the general kernel (the serial form of the recurrence) while the
+    # split chunk-parallel kernel holds them in one wave (round 4): the same numbers to rounding
+    monkeypatch.setenv("SOSRT_TRANSPORT", "ring")
+    probe = Solver(L, N, device=-1)
+    probe.set_grid(inputs.direction_grid(N))
+    ring_runs = probe.plan_launch(B, B)["transport"] == _lib.PLAN_TRANSPORT_RING
+    probe.close()
+    monkeypatch.delenv("SOSRT_TRANSPORT")
     if live.any():
-        assert np.array_equal(b.I[live], a.I[live])
+        if ring_runs:
+            assert np.array_equal(b.I[live], a.I[live])
+        else:
+            assert rel_err(b.I[live], a.I[live]) <= 1e-12
 
 
 def test_three_zone_columns_keep_their_bits_beside_columns_of_more_zones():

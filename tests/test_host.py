@@ -235,7 +235,11 @@ def test_launch_plan_of_the_order_loop():
     assert (p["transport"], p["repair"]) == (T.PLAN_TRANSPORT_FAST, 1)
     assert plan(501, 800, 1, 1, surface="lambertian")["transport"] == T.PLAN_TRANSPORT_FAST
     assert (plan(300, 96, 2, 2)["transport"], plan(300, 96, 2, 2)["parts"]) == (T.PLAN_TRANSPORT_SCAN, 5)
-    assert plan(70, 50, 4, 4)["transport"] == T.PLAN_TRANSPORT_GENERAL
+    # N = 70, 129, 257: the rewritten mu -> 0- directions straddle two waves of a half row, which no wave-independent kernel takes --
+    # but part 0 of the split form holds them in one wave: chunk-parallel kernel; the general kernel where there is no split form
+    assert (plan(70, 50, 4, 4)["transport"], plan(70, 50, 4, 4)["parts"]) == (T.PLAN_TRANSPORT_SCAN, 2)
+    assert (plan(257, 64, 2, 2)["transport"], plan(257, 64, 2, 2)["parts"]) == (T.PLAN_TRANSPORT_SCAN, 5)
+    assert plan(70, 50, 4, 4, surface="lambertian")["transport"] == T.PLAN_TRANSPORT_GENERAL
     # columns of more than three zones (two aerosol layers): ring-class kernels, dense contraction, no order-loop launch
     p = plan(128, 200, 40, 20, zones=5)
     assert (p["gemm"], p["transport"], p["order_loop"]) == (G.PLAN_GEMM_DENSE, T.PLAN_TRANSPORT_SCAN, 0)

@@ -196,9 +196,84 @@ def run_layers(cases=8, seed=1, verbose=True):
     return bad
 
 
+def run_wide(cases=10, seed=1, verbose=True):
+    """The same for the shapes of the chunk-parallel kernel's WIDE instantiation (round 4: odd N, N > 256, more than 64 chunks per
+    sweep -- the reference's shipped N = 501, L = 800 is all three): the default plan (WIDE, ceil(N / 64) workgroups per column)
+    and the register-streaming kernel of rounds 1-3 (SOSRT_TRANSPORT=fast) against the oracle at 1e-10 with equal order counts,
+    and against each other (different summation forms of the recurrence: rounding apart, no more)."""
+    rng = np.random.default_rng(seed + 7)
+    bad = 0
+    for case in range(cases):
+        N = int(rng.choice([129, 191, 257, 300, 333, 501]))
+        L = int(rng.choice([rng.integers(12, 90), rng.integers(12, 90), rng.integers(520, 700)])) if N <= 200 else int(rng.integers(12, 110))
+        z_up = float(rng.uniform(20, 100)); z_down = float(rng.uniform(5, z_up - 5))
+        B = 2
+        mu0 = rng.uniform(0.15, 1.0, B); taer = rng.choice([0.02, 0.1, 0.4, 1.0, 3.0], B); rho = rng.uniform(0.0, 0.8, B)
+        J = int(rng.choice([0, 20, 66, 90])); amp = float(rng.choice([0.003, 0.02, 0.3]))
+        mu = O.make_mu(N)
+        c = np.ones(2 * N)
+        c[N:] = np.where(np.arange(N) < J, 1 + amp * (-1.0) ** np.arange(N), 1.0)
+        P_atm = O.phase_rayleigh(N, mu, 0.5)[1] * c[:, None]
+        P_aer = O.phase_hg(N, mu, 0.5, float(rng.choice([0.5, 0.7, 0.85])))[1] * c[:, None]
+        P0a = np.stack([O.phase_rayleigh(N, mu, m)[0] for m in mu0]); P0r = np.stack([O.phase_hg(N, mu, m, 0.7)[0] for m in mu0])
+        kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=L, nb_angles=N, z_up=z_up, z_down=z_down, surface="specular",
+                  P_atm=P_atm, P_aer=P_aer, P0_atm=P0a, P0_aer=P0r, max_orders=60, raise_on_error=False)
+        out, msg = {}, []
+        for tag, env in (("wide", {}), ("fast", {"SOSRT_TRANSPORT": "fast"})):
+            _reset(env)
+            for s_ in list(M._solvers.values()):
+                s_.close()
+            M._solvers.clear()
+            try:
+                out[tag] = SOS_Aer_batch(mu0, taer, rho, **kw)
+            except ValueError as e:
+                out[tag] = e
+        if isinstance(out["wide"], Exception):
+            if verbose:
+                print("wide case %2d L=%3d N=%3d: %s" % (case, L, N, out["wide"]))
+            continue
+        w, f = out["wide"], out["fast"]
+        if not (np.array_equal(w.n, f.n) and np.array_equal(w.status, f.status)):
+            msg.append("orders / statuses differ between the kernels: %s %s vs %s %s" % (w.n.tolist(), w.status.tolist(), f.n.tolist(), f.status.tolist()))
+        worst, apart = 0.0, 0.0
+        for b in range(B):
+            col = O.make_column(mu0[b], 120, z_up, z_down, L, 0.124, taer[b], rho[b], 1.0, 0.95, N, P0a[b], P_atm, P0r[b], P_aer)
+            try:
+                ref = O.solve_column(col, literal=False, max_orders=60)
+            except IndexError:
+                for tag in out:
+                    if out[tag].status[b] != 1:
+                        msg.append("%s column %d: oracle raises IndexError, status %d" % (tag, b, out[tag].status[b]))
+                continue
+            for tag in out:
+                r = out[tag]
+                if r.status[b] == 2 and ref.n >= 60:
+                    continue
+                if r.status[b] != 0 or r.n[b] != ref.n:
+                    msg.append("%s column %d: status %d n %d (oracle %d)" % (tag, b, r.status[b], r.n[b], ref.n))
+                    continue
+                e = rel_err(r.I[b], ref.I)
+                worst = max(worst, e)
+                if not e <= 1e-10:
+                    noise = rel_err(O.first_order(col), O.first_order_extended(col))
+                    if not e <= 3 * noise:
+                        msg.append("%s column %d: rel err %.2e" % (tag, b, e))
+            if w.status[b] == 0 and f.status[b] == 0:
+                apart = max(apart, rel_err(w.I[b], f.I[b]))
+        bad += bool(msg)
+        if verbose or msg:
+            print("wide case %2d L=%3d N=%3d J=%2d amp=%.3f  orders %s  max rel err %.1e  kernels %.1e apart  %s" % (
+                case, L, N, J, amp, w.n.tolist(), worst, apart, "; ".join(msg) if msg else "ok"))
+    _reset({})
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    return bad
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    b = run(n, seed) + run_layers(max(n // 2, 1), seed)
+    b = run(n, seed) + run_layers(max(n // 2, 1), seed) + run_wide(max(n // 2, 1), seed)
     print("cases with a mismatch:", b)
     sys.exit(1 if b else 0)
