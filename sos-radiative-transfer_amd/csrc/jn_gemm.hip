@@ -41,6 +41,9 @@ namespace {
 #define SOSRT_DENSE_SLAB_RT 1
 #endif
 constexpr int DENSE_SLAB_RT = SOSRT_DENSE_SLAB_RT;
+#ifndef SOSRT_LIVE_TILE_MAJOR
+#define SOSRT_LIVE_TILE_MAJOR 1
+#endif
 constexpr int DENSE_SLAB_ROWS = 16 * DENSE_SLAB_RT;
 
 template <bool SYM>
@@ -90,7 +93,18 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     const int nct = (g.D + GEMM_BN - 1) / GEMM_BN;
     const int id = blockIdx.x;
     const int xq = (id / (8 * nct)) * 8 + (id & 7), bn0 = ((id >> 3) % nct) * GEMM_BN;
+#if SOSRT_LIVE_TILE_MAJOR
+    // Tile-major, the plain rows' tiles of every column first, the slab rows' 16-row tiles last: the last workgroups of a launch
+    // decide how long its last, partly filled round of workgroups takes, and with the combined slab matrices (one pass over k) the slab
+    // tiles are the short ones.  (Until round 3 a column's tiles were consecutive, slab tiles first -- from the time they made two
+    // passes over k.)
+    const int cap = g.live_cap > 0 ? g.live_cap : 1;
+    const int tq = xq / cap, ci = xq % cap;
+    if (tq >= ts + tm) return;                           // (uniform) padding of the grid
+    const int tt = tq < tm ? ts + tq : tq - tm;          // tt < ts: slab tile tt; else plain tile tt - ts
+#else
     const int ci = xq / (ts + tm), tt = xq % (ts + tm);
+#endif
     if (tid == 0) s_col = -1;
     int before = 0;
     for (int base = 0; base < g.B; base += 256) {
@@ -110,7 +124,9 @@ __device__ __forceinline__ void gemm_live_columns(const GemmArgs& g, double* sA,
     }
     const int b = s_col;
     // the transport of this order takes its columns from this list
-    if (g.live_list && tt == 0 && bn0 == 0 && tid == 0 && ci < g.live_cap) g.live_list[ci] = b < 0 ? -1 : b - g.col0;
+    if (g.live_list && xq < (SOSRT_LIVE_TILE_MAJOR ? (g.live_cap > 0 ? g.live_cap : 1) : 1 << 30) &&
+        (SOSRT_LIVE_TILE_MAJOR || tt == 0) && bn0 == 0 && tid == 0 && ci < g.live_cap)
+        g.live_list[ci] = b < 0 ? -1 : b - g.col0;
     if (b < 0) return;                                   // fewer live columns than the host's (lagging) count
     const int iu = g.idx_up ? g.idx_up[b] : 0;
     const int ns = g.idx_up ? g.idx_down[b] - iu + 1 : 0;
