@@ -32,6 +32,13 @@ namespace sosrt {
 
 namespace {
 
+// cache policy of the field rows' stores (In, I, saved) -- experiment of round 4 (-DSOSRT_RING_STORE_AUX=17: write-through, so that
+// the kernel leaves no dirty lines for the end-of-kernel write-back): default 0, plain stores
+#ifndef SOSRT_RING_STORE_AUX
+#define SOSRT_RING_STORE_AUX 0
+#endif
+__device__ __forceinline__ void rstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x) { bstore_aux<SOSRT_RING_STORE_AUX>(r, voff, soff, x); }
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr size_t kRingLdsBytes = 152 * 1024;               // of the 160 KiB of a CU
@@ -313,9 +320,9 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     const double IcT = ACC ? slot[(2 * TC + uT) * RS + max(mT, 0)] : 0.0;
                     if (pT < nfx) {
                         const int voT = (t0 + uT) * RB + mT * 8;
-                        bstore(rIn, voT, 0, acc);
-                        if (ACC) bstore(rI, voT, 0, IcT + acc);
-                        if (SAVED) bstore(rS, voT, 0, acc);
+                        rstore(rIn, voT, 0, acc);
+                        if (ACC) rstore(rI, voT, 0, IcT + acc);
+                        if (SAVED) rstore(rS, voT, 0, acc);
                     }
                 } else if (MODE == 2 && wl && nfx > 0) {
 #pragma unroll
@@ -330,9 +337,9 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         const int so = (t0 + u) * RB;
-                        bstore(rIn, vo, so, v[u]);
-                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
-                        if (SAVED) bstore(rS, vo, so, v[u]);
+                        rstore(rIn, vo, so, v[u]);
+                        if (ACC) rstore(rI, vo, so, Ic[u] + v[u]);
+                        if (SAVED) rstore(rS, vo, so, v[u]);
                     }
                 }
             } else {
@@ -353,9 +360,9 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     Dv = t < L ? (zone_end ? (stdl ? x : 0.0) : Dn) : Dv;
                     if (valid && t < L) {
                         const int so = t * RB;
-                        bstore(rIn, vo, so, x);
-                        if (ACC) bstore(rI, vo, so, Ic[u] + x);
-                        if (SAVED) bstore(rS, vo, so, x);
+                        rstore(rIn, vo, so, x);
+                        if (ACC) rstore(rI, vo, so, Ic[u] + x);
+                        if (SAVED) rstore(rS, vo, so, x);
                     }
                 }
             }
@@ -504,9 +511,9 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                         const double IcT = ACC ? slot[(2 * TC + uT) * RS + k] : 0.0;
                         if (k < N) {
                             const int voT = (t0 - uT) * RB + (N + k) * 8;
-                            bstore(rIn, voT, 0, val);
-                            if (ACC) bstore(rI, voT, 0, IcT + val);
-                            if (SAVED) bstore(rS, voT, 0, val);
+                            rstore(rIn, voT, 0, val);
+                            if (ACC) rstore(rI, voT, 0, IcT + val);
+                            if (SAVED) rstore(rS, voT, 0, val);
                         }
                     } else {
                         // (rare; stored here so that the rows are not updated conditionally: no copies at the join)
@@ -515,9 +522,9 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                             const double xb_ = blend(v[u], t0 - u);
                             if (valid) {
                                 const int so = (t0 - u) * RB;
-                                bstore(rIn, vo, so, xb_);
-                                if (ACC) bstore(rI, vo, so, Ic[u] + xb_);
-                                if (SAVED) bstore(rS, vo, so, xb_);
+                                rstore(rIn, vo, so, xb_);
+                                if (ACC) rstore(rI, vo, so, Ic[u] + xb_);
+                                if (SAVED) rstore(rS, vo, so, xb_);
                             }
                         }
                     }
@@ -526,9 +533,9 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
 #pragma unroll
                     for (int u = 0; u < TC; ++u) {
                         const int so = (t0 - u) * RB;
-                        bstore(rIn, vo, so, v[u]);
-                        if (ACC) bstore(rI, vo, so, Ic[u] + v[u]);
-                        if (SAVED) bstore(rS, vo, so, v[u]);
+                        rstore(rIn, vo, so, v[u]);
+                        if (ACC) rstore(rI, vo, so, Ic[u] + v[u]);
+                        if (SAVED) rstore(rS, vo, so, v[u]);
                     }
                 }
             } else {
@@ -543,9 +550,9 @@ __global__ __launch_bounds__(512) void k_transport_ring(TransportArgs a, int NS,
                     U = t >= 0 ? ((zone_start && tr) ? x : Un) : U;
                     if (valid && t >= 0) {
                         const int so = t * RB;
-                        bstore(rIn, vo, so, x);
-                        if (ACC) bstore(rI, vo, so, Ic[u] + x);
-                        if (SAVED) bstore(rS, vo, so, x);
+                        rstore(rIn, vo, so, x);
+                        if (ACC) rstore(rI, vo, so, Ic[u] + x);
+                        if (SAVED) rstore(rS, vo, so, x);
                     }
                 }
             }
