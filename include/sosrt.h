@@ -133,7 +133,8 @@ int sosrt_set_contraction(sosrt_t* h, int mode);
  * counters in device memory; the host only waits for the launch's report.  Same arithmetic, same bits.  mode 0 (default): never --
  * measured on MI355X the launch is bit-identical but SLOWER than the two launches per order it replaces (the dependency chain
  * sweep -> source-function tile -> sweep is the same; DESIGN section 5 item 9, profiles/r04_order_loop_ab_v0.txt); mode 1: where
- * the launch plan says so (sosrt_plan_launch), kept for the measurements and as the scaffold of a finer-grained pipeline.  The launch checks its own residency first and hands the orders back
+ * the launch plan says so (sosrt_plan_launch), kept for the measurements and as the scaffold of a finer-grained pipeline; mode 2
+ * (tests): as 1 with a grid of twice the device's CUs, which can never be resident -- every launch is refused and handed back.  The launch checks its own residency first and hands the orders back
  * to the two-launch loop when another process's kernels keep its grid from being resident (sosrt_order_loop_stats: launches of
  * the last solve, how many of them were refused that way, and the (column, order) pairs that ran inside them). */
 int sosrt_set_order_loop(sosrt_t* h, int mode);

@@ -751,7 +751,7 @@ int sosrt_set_contraction(sosrt_t* h, int mode) {
 
 int sosrt_set_order_loop(sosrt_t* h, int mode) {
     if (!h) return fail(SOSRT_E_INVALID, "null handle");
-    if (mode != 0 && mode != 1) return fail(SOSRT_E_INVALID, "order-loop mode must be 0 or 1 (got %d)", mode);
+    if (mode < 0 || mode > 2) return fail(SOSRT_E_INVALID, "order-loop mode must be 0, 1 or 2 (got %d)", mode);
     h->order_loop = mode;
     return 0;
 }
@@ -1452,6 +1452,9 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 if (got == 0) { oi.cu_share = 0; pl = plan_order(h, shape, oi); }
                 else { pl.ol_grid = got; ol_held[k] = got; }
             }
+            // (mode 2, for the tests of the refusal path: a grid of twice the CUs can never be resident -- the handshake times out,
+            // nothing has been touched, and the order is run as two launches)
+            if (pl.order_loop && h->order_loop == 2) pl.ol_grid = 2 * h->cu_count;
             if (pl.order_loop) {
                 OrderLoopArgs oa;
                 Grid gt = g;

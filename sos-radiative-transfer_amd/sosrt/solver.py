@@ -92,7 +92,7 @@ class Solver:
     def set_order_loop(self, on=True):
         """Whether the last orders of the last few live columns run in ONE launch (csrc/order_loop.hip; default on: same
         bits, no launches and no host round trip per order) or every order stays two launches."""
-        check(lib().sosrt_set_order_loop(self._h, 1 if on else 0))
+        check(lib().sosrt_set_order_loop(self._h, int(on) if on in (0, 1, 2) else (1 if on else 0)))
 
     def order_loop_stats(self, column_orders=False):
         """(order-loop launches of the last solve, launches that found their grid not resident and handed back[, the (column,

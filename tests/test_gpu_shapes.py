@@ -462,6 +462,84 @@ def test_order_loop_kernel_keeps_the_bits(L, N, B, surface, monkeypatch):
     assert np.array_equal(a.I, b.I)                                            # bit for bit
 
 
+def test_a_refused_order_loop_launch_hands_the_orders_back():
+    """The residency handshake of an order-loop launch, made to fail on purpose (mode 2: a grid of twice the device's CUs): every
+    workgroup that is on the machine waits 4 ms for the ones that are not, one of them declares the launch NOT RESIDENT, nothing
+    has been touched, and the host runs the same orders as two launches each -- same bits, one refused launch per solve (no
+    second attempt within a solve)."""
+    rng = np.random.default_rng(17)
+    B, L, N = 6, 72, 128
+    mu0 = rng.uniform(0.2, 1.0, B); taer = rng.choice([0.02, 0.12, 0.6], B); rho = rng.uniform(0.0, 0.8, B)
+    mu = inputs.direction_grid(N)
+    P0a, Pa = inputs.phase_function("rayleigh", N, mu, 0.5); P0r, Pr = inputs.phase_function("hg", N, mu, 0.5, 0.7)
+    P0a = np.stack([inputs.phase_function("rayleigh", N, mu, m)[0] for m in mu0]); P0r = np.stack([inputs.phase_function("hg", N, mu, m, 0.7)[0] for m in mu0])
+    iu, idn = inputs.slab_indices(120, 25, 17, L)
+    tau = np.stack([inputs.tau_profile(0.124, t, 120, 25, 17, L) for t in taer])
+    out = {}
+    for mode in (0, 2, 1):
+        s = Solver(L, N, max_batch=B, max_orders=100)
+        s.set_grid(mu); s.set_phase(Pa, Pr)
+        s.set_columns(np.full(B, iu), np.full(B, idn), mu0, rho, 1.0, 0.95, 0.124 / L, taer / (idn + 1 - iu), 0.124 + taer)
+        s.set_order_loop(mode)
+        out[mode] = (s.solve(tau, P0a, P0r), s.order_loop_stats(True))
+        s.close()
+    ref = out[0][0]
+    assert out[0][1] == (0, 0, 0)
+    assert out[2][1] == (1, 1, 0), out[2][1]                 # launched once, refused, no (column, order) ran inside it
+    assert out[1][1][0] == 1 and out[1][1][1] == 0 and out[1][1][2] == int((ref.n - 1).sum())
+    for mode in (1, 2):
+        r = out[mode][0]
+        assert np.array_equal(r.n, ref.n) and np.array_equal(r.status, ref.status) and np.array_equal(r.I, ref.I), mode
+
+
+_OL_WORKER = r"""
+import json, os, sys
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "sos-radiative-transfer_amd"))
+from sosrt import main as M
+from sosrt.main import SOS_Aer_batch
+rng = np.random.default_rng(5)
+B = 24
+mu0 = rng.uniform(0.2, 1.0, B); taer = rng.choice([0.02, 0.12, 0.6], B); rho = rng.uniform(0.0, 0.8, B)
+kw = dict(tauStar_atm=0.124, alb_aer=0.95, nb_layers=200, nb_angles=128, max_orders=200)
+os.environ["SOSRT_ORDER_LOOP"] = "0"
+ref = SOS_Aer_batch(mu0, taer, rho, **kw)
+for s_ in list(M._solvers.values()):
+    s_.close()
+M._solvers.clear()
+os.environ["SOSRT_ORDER_LOOP"] = "1"
+launches = refused = 0
+for it in range(int(sys.argv[2])):
+    r = SOS_Aer_batch(mu0, taer, rho, **kw)
+    assert np.array_equal(r.n, ref.n) and np.array_equal(r.status, ref.status) and np.array_equal(r.I, ref.I), it
+    st = list(M._solvers.values())[0].order_loop_stats()
+    launches += st[0]; refused += st[1]
+print(json.dumps({"launches": launches, "refused": refused}))
+"""
+
+
+def test_order_loop_launches_of_two_processes_on_one_gpu():
+    """An order-loop launch is workgroups that wait for each other, so all of them must be on the machine -- which another process's
+    kernels can prevent (the per-device CU budget only spans the handles of ONE process).  Two processes solve with
+    SOSRT_ORDER_LOOP=1 on the one GPU at the same time, forty solves each: whenever a launch finds its grid not resident (its
+    handshake times out; nothing has been touched) the host takes the orders back with two launches each, and every solve of both
+    processes has the bits of the two-launch loop.  The refused launches are reported, not asserted (they depend on how the two
+    processes' launches interleave)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", _OL_WORKER, root, "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    stats = [json.loads([l for l in so.splitlines() if l.startswith("{")][-1]) for so, _ in outs]
+    print("order-loop launches / refused per process:", stats)
+    assert all(st["launches"] >= 40 for st in stats)
+
+
 @pytest.mark.parametrize("L,N", [(3, 8), (4, 64), (5, 128), (8, 32), (9, 128), (17, 100), (33, 64), (65, 128),
                                  (40, 256), (26, 192), (21, 200), (200, 256)])
 def test_chunk_parallel_transport_on_small_and_ragged_shapes(L, N, monkeypatch):
