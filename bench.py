@@ -321,6 +321,7 @@ def measure_strong(a, dev, local_rank, rank, world, on_gpu):
     import torch
     import torch.distributed as dist
     from sosrt import dist as sdist
+    torch.cuda.set_device(local_rank)                          # (the current device is per thread: this runs in one of its own)
     w1 = build_sweep(a.columns, a.layers, a.angles, 0, 1, vary_albedo=False, aerosol=a.aerosol)
     plan = sdist.GatherPlan(w1["B"], world, sdist.expected_orders(w1["tau_atm"] + w1["taer"], w1["rho"]))
     mine = plan.mine(rank)
@@ -653,9 +654,8 @@ def main():
     # Several GPUs, weak-scaling headline: the same command also measures BASELINE configs[3] -- ONE sweep over the node, dealt to
     # the ranks by expected work (sosrt.dist.GatherPlan), the whole fields gathered to rank 0 once per step (through the C ABI's
     # sosrt_gather under RCCL; torch.distributed point-to-point in the gloo rehearsal) -- so that one driver run yields both curves.
+    # (measured AFTER every collective of the weak-scaling headline below, under a watchdog: the headline must not depend on it)
     strong_obj = None
-    if world > 1 and not strong:
-        strong_obj = measure_strong(a, dev, local_rank, rank, world, on_gpu)
 
     cpu_t = dev if on_gpu else "cpu"
     t = torch.tensor([dt], dtype=torch.float64, device=cpu_t)
@@ -821,11 +821,33 @@ def main():
             out["strong"] = {"status": "unmeasured: one GPU.  With --gpus N this object holds the one-sweep-over-the-node measurement of "
                                        "BASELINE configs[3] (512 columns dealt to the ranks, fields gathered to rank 0)",
                              "single_gpu_proxy": "extras.c4_shard"}
-        elif strong_obj is not None:
-            out["strong"] = strong_obj
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
+    stuck = False
+    if world > 1 and not strong:
+        # The one-sweep-over-the-node measurement, in a thread the main thread waits for with a limit: its gather (the C ABI's
+        # sosrt_gather under RCCL) has never run with more than one rank on this pool's one-GPU boxes, and a collective that does not
+        # complete must cost the line its `strong` object, not the line.
+        import threading
+        box = {}
+
+        def _strong():
+            try:
+                box["obj"] = measure_strong(a, dev, local_rank, rank, world, on_gpu)
+            except Exception as e:                      # (on every rank alike, or the others run into the limit)
+                box["obj"] = {"status": "failed: %s: %s" % (type(e).__name__, e)}
+
+        th = threading.Thread(target=_strong, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("SOSRT_BENCH_STRONG_LIMIT", "240")))
+        stuck = th.is_alive()
+        strong_obj = {"status": "timed out: the strong-scaling measurement did not complete within its limit"} if stuck else box.get("obj")
+    if rank == 0:
+        if world > 1 and strong_obj is not None:
+            out["strong"] = strong_obj
         print(json.dumps(out), flush=True)
+    if stuck:
+        os._exit(0)                                     # (a collective is still pending: no orderly shutdown of the process group)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
