@@ -65,7 +65,8 @@ def run(cases=24, seed=1, verbose=True):
             r = out[tag]
             if tag in ("scan", "scan1") and not (np.array_equal(r.n, ring.n) and np.array_equal(r.status, ring.status)
                                                  and np.array_equal(r.I[ring.status == 0], ring.I[ring.status == 0])):
-                msg.append("%s differs from ring in bits" % tag)
+                if _ring_runs(L, N, out[tag].I.shape[0], 3):
+                    msg.append("%s differs from ring in bits" % tag)
         worst, long_rows, note = 0.0, 0, ""
         for b in range(B):
             noise = None
@@ -111,6 +112,24 @@ def run(cases=24, seed=1, verbose=True):
     return bad
 
 
+def _ring_runs(L, N, B, zones=3):
+    """Whether SOSRT_TRANSPORT=ring runs the ring kernel at this shape (else the general kernel: rounding apart from the
+    chunk-parallel one, which takes every N > 64 since round 4)."""
+    from sosrt.solver import Solver
+    from sosrt import _lib, inputs
+    keep = os.environ.get("SOSRT_TRANSPORT")
+    os.environ["SOSRT_TRANSPORT"] = "ring"
+    s = Solver(L, N, device=-1)
+    s.set_grid(inputs.direction_grid(N))
+    ok = s.plan_launch(B, B, zones=zones)["transport"] == _lib.PLAN_TRANSPORT_RING
+    s.close()
+    if keep is None:
+        os.environ.pop("SOSRT_TRANSPORT", None)
+    else:
+        os.environ["SOSRT_TRANSPORT"] = keep
+    return ok
+
+
 def _reset(env):
     for k in ("SOSRT_TRANSPORT", "SOSRT_SCAN_SPLIT"):
         os.environ.pop(k, None)
@@ -124,7 +143,9 @@ def run_layers(cases=8, seed=1, verbose=True):
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(cases):
-        N = int(rng.choice([64, 100, 128, 128, 192, 256]))
+        # (70, 130, 200: direction counts whose rewritten mu -> 0- directions straddle two waves of a half row -- the split
+        # chunk-parallel kernel's since round 4, in its zone-table instantiation here)
+        N = int(rng.choice([64, 70, 100, 128, 128, 130, 192, 200, 256]))
         L = int(rng.integers(40, 120))
         nsl = int(rng.choice([2, 2, 3]))
         # layer tops and bottoms from the top of the atmosphere down, clear air between them
@@ -159,7 +180,8 @@ def run_layers(cases=8, seed=1, verbose=True):
             r = out.get(tag)
             if r is not None and not (np.array_equal(r.n, ring.n) and np.array_equal(r.status, ring.status)
                                       and np.array_equal(r.I[ring.status == 0], ring.I[ring.status == 0])):
-                msg.append("%s differs from ring in bits" % tag)
+                if _ring_runs(L, N, out[tag].I.shape[0], 2 * nsl + 1):
+                    msg.append("%s differs from ring in bits" % tag)
         worst, note = 0.0, ""
         for b in range(B):
             noise = None
