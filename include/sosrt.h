@@ -85,6 +85,10 @@ int sosrt_synchronize(sosrt_t* h);
  * max_orders; orders beyond are computed but not stored).  Default: max_orders.  The reference's list
  * I_saved (spec:304-305,458) has exactly n entries: solve once without it to learn n, then once with slots = max n. */
 int sosrt_set_saved_orders(sosrt_t* h, int slots);
+/* The solves that follow run at most `max_orders` orders (1 <= max_orders <= the max_orders of sosrt_create, which is the default):
+ * a column still iterating then has status SOSRT_COL_MAXORDERS.  (The reference's loop, spec:309, has no bound.)  Lets one handle
+ * serve callers with different budgets -- the Python layer's handle cache does. */
+int sosrt_set_order_budget(sosrt_t* h, int max_orders);
 
 /* ---- per-sweep setup ------------------------------------------------------------------------ */
 /* direction grid mu[2N] (spec:59-61).  Builds the trapezoid weights of np.trapz(.., mu) used by

@@ -58,6 +58,7 @@ struct Prof {
 
 struct sosrt_handle {
     int device = -1, L = 0, N = 0, D = 0, max_batch = 0, max_orders = 0;
+    int order_budget = 0;                // orders a solve runs at most (sosrt_set_order_budget; <= max_orders, the default)
     int saved_slots = 0;                 // orders per column in I_saved_out (sosrt_set_saved_orders; default max_orders)
     bool gpu = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -564,6 +565,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     sosrt_handle* h = new (std::nothrow) sosrt_handle();
     if (!h) return fail(SOSRT_E_NOMEM, "out of host memory");
     h->device = device; h->L = L; h->N = N; h->D = 2 * N; h->max_batch = max_batch; h->max_orders = max_orders;
+    h->order_budget = max_orders;
     h->saved_slots = max_orders;
     h->gpu = device >= 0;
     h->cu_count = 256;                       // (a host-only handle plans for an MI355X; a device handle asks the device below)
@@ -724,6 +726,14 @@ int sosrt_set_saved_orders(sosrt_t* h, int slots) {
     if (!h) return fail(SOSRT_E_INVALID, "null handle");
     if (slots < 1 || slots > h->max_orders) return fail(SOSRT_E_INVALID, "slots must be in 1..max_orders=%d (got %d)", h->max_orders, slots);
     h->saved_slots = slots;
+    return 0;
+}
+
+int sosrt_set_order_budget(sosrt_t* h, int max_orders) {
+    if (!h) return fail(SOSRT_E_INVALID, "null handle");
+    if (max_orders < 1 || max_orders > h->max_orders)
+        return fail(SOSRT_E_INVALID, "the order budget must be in 1..max_orders=%d of sosrt_create (got %d)", h->max_orders, max_orders);
+    h->order_budget = max_orders;
     return 0;
 }
 
@@ -1427,7 +1437,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 start_group(k);
             }
             progressed = true;
-            if (q.n >= h->max_orders) { q.done = true; --live_groups; continue; }
+            if (q.n >= h->order_budget) { q.done = true; --live_groups; continue; }
             if (q.n >= 2) {
                 const int live = wait_published(h, k, tagbase + q.n - 1);
                 if (live < 0) return bail(live);
@@ -1443,7 +1453,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             oi.nb = q.nb; oi.known = q.known; oi.surface = h->surface;
             oi.simple_zones = h->simple_zones; oi.slabs_mixed = h->nslab == 0 || h->mix_groups > 0;
             oi.need_small = g.nsmall > 0 && h->need_small; oi.saving = d_I_saved_out != nullptr;
-            oi.orders_left = h->max_orders - q.n;
+            oi.orders_left = h->order_budget - q.n;
             oi.cu_share = q.ol_off ? 0 : h->cu_count / NG;
             LaunchPlan pl = plan_order(h, shape, oi);
             if (pl.order_loop) {
@@ -1475,7 +1485,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 oa.gbufP = q.In;
                 oa.gbufQ = (q.In_1 == d_I_out) ? h->d_InA : q.In_1;   // (after the second order: the buffer the first order left unused)
                 oa.bufP = oa.gbufP + fo; oa.bufQ = oa.gbufQ + fo;
-                oa.order0 = q.n + 1; oa.kmax = h->max_orders - q.n;
+                oa.order0 = q.n + 1; oa.kmax = h->order_budget - q.n;
                 oa.B = q.nb; oa.col0 = q.b0;
                 oa.fixcap = (int)(0.06 * g.N) + 1;
                 oa.sync = h->d_olsync + (size_t)k * order_loop_sync_ints(kOrderLoopMaxCols);
@@ -1538,7 +1548,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     prof_break(h);
-    launch_finalize(s, B, make_conv(h, tol), h->max_orders, d_n_orders_out, d_status_out);
+    launch_finalize(s, B, make_conv(h, tol), h->order_budget, d_n_orders_out, d_status_out);
     HIPCHK(hipGetLastError());
     h->last_max_orders = used_order_loop ? -1 : n_max;      // (orders run inside an order-loop launch: read back with the counts)
     h->last_sum_orders = -1;

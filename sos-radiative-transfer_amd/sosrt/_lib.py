@@ -34,6 +34,7 @@ SIGNATURES = {
     "sosrt_use_own_stream": (c_int, [c_void_p]),
     "sosrt_synchronize": (c_int, [c_void_p]),
     "sosrt_set_saved_orders": (c_int, [c_void_p, c_int]),
+    "sosrt_set_order_budget": (c_int, [c_void_p, c_int]),
     "sosrt_set_contraction": (c_int, [c_void_p, c_int]),
     "sosrt_phase_asymmetry": (c_int, [c_void_p, POINTER(c_double), _ip]),
     "sosrt_set_order_loop": (c_int, [c_void_p, c_int]),

@@ -61,6 +61,8 @@ def get_solver(nb_layers, nb_angles, batch, max_orders, device=0) -> Solver:
         if s is not None:
             s.close()
         s = _solvers[key] = Solver(nb_layers, nb_angles, max_batch=batch, max_orders=max_orders, device=device)
+    if s.order_budget != max_orders:                 # (a cached handle made for a larger budget serves this call with its own)
+        s.set_order_budget(max_orders)
     return s
 
 

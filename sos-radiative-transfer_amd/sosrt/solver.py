@@ -53,6 +53,7 @@ class Solver:
         self._h = ctypes.c_void_p()
         check(lib().sosrt_create(self.device, self.L, self.N, self.max_batch, self.max_orders, ctypes.byref(self._h)))
         self.B = 0
+        self.order_budget = self.max_orders
         self.mu = None
         self._P = (None, None)
 
@@ -88,6 +89,12 @@ class Solver:
         if m is None:
             raise ValueError("contraction must be 'f64', 'f64_full' or 'f32'")
         check(lib().sosrt_set_contraction(self._h, m))
+
+    def set_order_budget(self, max_orders: int):
+        """The solves that follow run at most `max_orders` orders (<= the handle's max_orders); a column still iterating then
+        has status COL_MAXORDERS."""
+        check(lib().sosrt_set_order_budget(self._h, int(max_orders)))
+        self.order_budget = int(max_orders)
 
     def set_order_loop(self, on=True):
         """Whether the last orders of the last few live columns run in ONE launch (csrc/order_loop.hip; default on: same

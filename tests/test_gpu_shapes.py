@@ -65,6 +65,14 @@ def test_order_budget_is_reported():
                        atm_phase_fun="iso", aer_phase_fun="iso", max_orders=64)
     if r.status[0] == _lib.COL_OK:
         assert r.n[0] == ok.n[0] and np.array_equal(r.I[0], ok.I[0])
+    # the budget is the CALL's, not that of the cached handle, which was just remade for 64 orders (sosrt_set_order_budget)
+    again = SOS_Aer_batch([0.5, 0.5], [0.05, 1.0], [0.1, 0.7], nb_layers=L, nb_angles=N, z_up=60, z_down=20, P_atm=P, P_aer=P,
+                          atm_phase_fun="iso", aer_phase_fun="iso", max_orders=6, raise_on_error=False)
+    assert again.status[1] == _lib.COL_MAXORDERS and again.n[1] == 6 and np.array_equal(again.I, r.I)
+    s = Solver(L, N, max_orders=8, device=-1)
+    with pytest.raises(ValueError):
+        s.set_order_budget(9)
+    s.close()
 
 
 def test_saved_orders_on_device_path_and_stats():
