@@ -24,14 +24,14 @@ __global__ __launch_bounds__(768) void k_transport_scan(TransportArgs a, int fix
 // shapes of the split form that take its WIDE instantiation (transport_scan_body.hpp): odd N, N > 256, more than 64 chunks per sweep
 inline bool scan_wide(const Grid& g) { return (g.N & 1) || g.N > 256 || (g.L + TC - 1) / TC > 64; }
 
-// the WIDE instantiation of the split form (three zones, with or without saved orders)
+// the WIDE instantiation of the split form (with or without saved orders; columns of three zones, or of up to a.nzcap: ZoneRows<true>)
 void launch_scan_wide(hipStream_t s, dim3 grid, const TransportArgs& a) {
     using C = ScanCfg<true, true>;
     const dim3 block((C::SW + NLOAD) * 64);
-    const size_t shm = scan_lds_bytes<true, true>(a.g, kRingZones);
-#define SOSRT_SCAN_LAUNCH_W(SAVED_)                                                                            \
+    const size_t shm = scan_lds_bytes<true, true>(a.g, a.nzcap);
+#define SOSRT_SCAN_LAUNCH_W(SAVED_, MZ_)                                                                       \
     do {                                                                                                       \
-        auto kern = k_transport_scan<true, SAVED_, true, 0, false, true>;                                      \
+        auto kern = k_transport_scan<true, SAVED_, true, 0, MZ_, true>;                                        \
         static bool big_lds = false;                                                                           \
         if (!big_lds) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -40,8 +40,11 @@ void launch_scan_wide(hipStream_t s, dim3 grid, const TransportArgs& a) {
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
     } while (0)
-    if (a.saved) SOSRT_SCAN_LAUNCH_W(true);
-    else SOSRT_SCAN_LAUNCH_W(false);
+    const bool mz = a.nzcap > kRingZones;
+    if (a.saved && mz) SOSRT_SCAN_LAUNCH_W(true, true);
+    else if (a.saved) SOSRT_SCAN_LAUNCH_W(true, false);
+    else if (mz) SOSRT_SCAN_LAUNCH_W(false, true);
+    else SOSRT_SCAN_LAUNCH_W(false, false);
 #undef SOSRT_SCAN_LAUNCH_W
 }
 
@@ -103,7 +106,7 @@ bool transport_scan_split_ok(const Grid& g) {
 int transport_scan_parts(const Grid& g) { return (g.N + 63) / 64; }
 // whether the per-zone tables of a batch whose columns have up to nzcap zones still fit beside the stages
 bool transport_scan_fits(const Grid& g, int nzcap, bool split) {
-    if (split && scan_wide(g)) return nzcap <= kRingZones && scan_lds_bytes<true, true>(g) <= kScanLdsBytes;     // (three zones only)
+    if (split && scan_wide(g)) return scan_lds_bytes<true, true>(g, nzcap) <= kScanLdsBytes;
     return (split ? scan_lds_bytes<true>(g, nzcap) : scan_lds_bytes<false>(g, nzcap)) <= kScanLdsBytes;
 }
 size_t transport_scan_scratch_doubles() { return kScanScratch; }

@@ -126,7 +126,7 @@ __device__ __forceinline__ bool fused_wait_ge(const int* p, int want, int* abort
 
 template <bool ACC, bool SAVED, bool SPLIT, int NC = 0, bool MZ = false, bool FUSED = false, bool WIDE = false>
 __device__ __forceinline__ int transport_scan_order(const TransportArgs& a, int fixcap, const int b, const int part, const ScanFused& fu) {
-    static_assert(!WIDE || (SPLIT && !MZ && !FUSED && NC == 0), "WIDE is an instantiation of the plain split form");
+    static_assert(!WIDE || (SPLIT && !FUSED && NC == 0), "WIDE is an instantiation of the plain split form");
     using Cfg = ScanCfg<SPLIT, WIDE>;
     constexpr int SW = Cfg::SW, NST = Cfg::NST, SROW = Cfg::SROW, STAGE = Cfg::STAGE;
     // SPLIT: ceil(N / 64) workgroups per column (two at N = 128, four at N = 256), part p

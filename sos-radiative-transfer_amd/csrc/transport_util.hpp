@@ -168,14 +168,23 @@ template <bool MZ> struct ZoneRows {
         return z;
     }
     __device__ __forceinline__ int nfix(int zz) const { return dg->nfix[zz]; }
-    // the same for sweeps of more than 64 chunks: bits of the chunks 64 word .. 64 word + 63 (the reference's zones only)
+    // the same for sweeps of more than 64 chunks: bits of the chunks 64 word .. 64 word + 63
     __device__ __forceinline__ unsigned long long boundary_chunks(int L, int tc, bool up, int word) const {
         unsigned long long m = 0;
-        const int rows[4] = {zend0, zend1, zbeg1, zbeg2};
+        if constexpr (!MZ) {
+            const int rows[4] = {zend0, zend1, zbeg1, zbeg2};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = (up ? L - 1 - rows[i] : rows[i]) / tc;
-            if (rows[i] >= 0 && (c >> 6) == word) m |= 1ull << (c & 63);
+            for (int i = 0; i < 4; ++i) {
+                const int c = (up ? L - 1 - rows[i] : rows[i]) / tc;
+                if (rows[i] >= 0 && (c >> 6) == word) m |= 1ull << (c & 63);
+            }
+        } else {
+            for (int k = 1; k < nz; ++k) {
+                const int rb = dg->r0[k], re = rb - 1;            // first row of zone k, last row of zone k - 1
+                const int cb = (up ? L - 1 - rb : rb) / tc, ce = (up ? L - 1 - re : re) / tc;
+                if ((cb >> 6) == word) m |= 1ull << (cb & 63);
+                if ((ce >> 6) == word) m |= 1ull << (ce & 63);
+            }
         }
         return m;
     }

@@ -764,6 +764,31 @@ def test_float_contraction_is_an_opt_in_that_misses_the_parity_bar():
     s.close()
 
 
+@pytest.mark.parametrize("L,N,slabs", [
+    (96, 201, [(60, 50, 0.2, 0.90), (25, 17, 0.4, 0.97)]),                          # odd N, five zones: four workgroups per column
+    (80, 300, [(80, 70, 0.05, 1.0), (55, 40, 0.3, 0.9), (25, 10, 0.6, 0.85)]),      # N > 256, seven zones
+    (560, 66, [(100, 90, 0.1, 0.95), (12, 5, 0.5, 0.9)]),                           # 70 chunks per sweep: boundaries in both mask words
+])
+def test_zone_table_columns_at_the_wide_shapes(L, N, slabs):
+    """Columns with several aerosol layers at the shapes of the chunk-parallel kernel's WIDE instantiation (odd N, N > 256, more than
+    64 chunks per sweep): the launch plan takes that kernel with the whole zone table (no longer the register-streaming fallback),
+    and the field matches the oracle's zone-table path (parity unpinned by construction: the reference has one layer)."""
+    from sosrt.main import SOS_Aer_layers, get_solver
+    mu = inputs.direction_grid(N)
+    m0 = np.array([0.45, 0.8]); rho = np.array([0.1, 0.5])
+    r = SOS_Aer_layers(m0, rho, slabs, nb_layers=L, nb_angles=N, max_orders=120)
+    nz = 2 * len(slabs) + 1
+    p = get_solver(L, N, 2, 120, 0).plan_launch(2, 2, zones=nz)
+    assert (p["transport"], p["parts"]) == (_lib.PLAN_TRANSPORT_SCAN, (N + 63) // 64)
+    Pa = inputs.phase_function("rayleigh", N, mu, 0.5)[1]; Pr = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    for i in range(2):
+        P0a = inputs.phase_function("rayleigh", N, mu, m0[i])[0]; P0r = inputs.phase_function("hg", N, mu, m0[i], 0.7)[0]
+        c = O.make_column_slabs(m0[i], 120, slabs, L, 0.124, rho[i], 1.0, N, P0a, Pa, P0r, Pr)
+        ref = O.solve_column(c, literal=False)
+        assert int(r.n[i]) == ref.n and int(r.status[i]) == 0
+        assert_close(r.I[i], ref.I, RTOL, "%d-zone column %d at L=%d, N=%d" % (nz, i, L, N))
+
+
 def test_zone_table_columns():
     """columns described by a zone table.  (clear, slab, clear) through sosrt_set_columns_zones equals
     sosrt_set_columns bit for bit; columns with two aerosol layers (five zones; the ring / chunk-parallel kernels in their

@@ -243,6 +243,9 @@ def test_launch_plan_of_the_order_loop():
     # columns of more than three zones (two aerosol layers): ring-class kernels, dense contraction, no order-loop launch
     p = plan(128, 200, 40, 20, zones=5)
     assert (p["gemm"], p["transport"], p["order_loop"]) == (G.PLAN_GEMM_DENSE, T.PLAN_TRANSPORT_SCAN, 0)
+    # ... at the shipped size and at an odd N as well (the WIDE instantiation with the whole zone table)
+    assert (plan(501, 800, 2, 2, zones=7)["transport"], plan(501, 800, 2, 2, zones=7)["parts"]) == (T.PLAN_TRANSPORT_SCAN, 8)
+    assert (plan(201, 120, 3, 3, zones=5)["transport"], plan(201, 120, 3, 3, zones=5)["parts"]) == (T.PLAN_TRANSPORT_SCAN, 4)
     # a smaller device: the launch is sized by its CUs
     p = plan(128, 200, 16, 16, cus=64)
     assert (p["order_loop"], p["ol_parts"], p["ol_grid"]) == (1, 2, 64)

@@ -145,7 +145,7 @@ def run_layers(cases=8, seed=1, verbose=True):
     for case in range(cases):
         # (70, 130, 200: direction counts whose rewritten mu -> 0- directions straddle two waves of a half row -- the split
         # chunk-parallel kernel's since round 4, in its zone-table instantiation here)
-        N = int(rng.choice([64, 70, 100, 128, 128, 130, 192, 200, 256]))
+        N = int(rng.choice([64, 70, 100, 128, 128, 130, 131, 192, 200, 256, 300]))
         L = int(rng.integers(40, 120))
         nsl = int(rng.choice([2, 2, 3]))
         # layer tops and bottoms from the top of the atmosphere down, clear air between them
