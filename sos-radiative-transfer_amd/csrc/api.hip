@@ -1301,14 +1301,11 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         small_published = true;
     }
     if (int e = ensure_matrices(h, s)) return e;
-    if (NG > 1) {                                    // the second column group runs on the internal stream from here on
-        HIPCHK(hipEventRecord(h->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    }
+    bool forked = false;
     // an error return after the fork still joins the internal stream back onto the caller's
     int ol_held[sosrt_handle::kMaxGroups] = {0, 0};          // CUs this solve's order-loop launches hold (ol_acquire)
     auto bail = [&](int code) {
-        if (NG > 1 && hipEventRecord(h->ev_join, h->stream2) == hipSuccess) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+        if (forked && hipEventRecord(h->ev_join, h->stream2) == hipSuccess) (void)hipStreamWaitEvent(s, h->ev_join, 0);
         for (int k = 0; k < NG; ++k)
             if (ol_held[k]) {                                 // (a launch still running keeps its CUs until its stream has drained)
                 (void)hipStreamSynchronize(group_stream(h, k));
@@ -1370,6 +1367,14 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
         prof_end(h, SOSRT_K_FIRST, k);
     };
     start_group(0);
+    if (NG > 1) {
+        // The second column group runs on the internal stream from here on.  The fork comes BEHIND the first group's first order:
+        // the two calls cost the host ~25 us, which the GPU -- 20 us of setup kernels ahead of the host at this point -- would
+        // otherwise wait for; the second group starts half a cycle after the first anyway.
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        forked = true;
+    }
     if (small_published && g.nsmall > 0) {
         // k_prepare's verdict on k_smallmu, published by the second kernel of the solve: by now it has long run
         volatile int* slot = h->h_pub + 8 * sosrt_handle::kMaxGroups;
