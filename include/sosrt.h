@@ -281,6 +281,8 @@ int sosrt_plan_fix_count(double tau_ref, int N);  /* I1_In:124-127 */
 #define SOSRT_PLAN_GEMM_LIVE64       1   /* tiles laid over the live columns, 64 rows                                           */
 #define SOSRT_PLAN_GEMM_LIVE32       2   /* ... 32 rows (at most 200 live columns)                                              */
 #define SOSRT_PLAN_GEMM_LIVE32_DEEP  3   /* ... both operands staged two chunks ahead (at most 32 live columns)                */
+#define SOSRT_PLAN_GEMM_LIVE16_REGS  4   /* ... 16 rows, a lane's matrix fragments in registers, no barrier in the k-loop (the   */
+                                         /*     last few live columns of the symmetric form: a tile's latency is the launch's)    */
 #define SOSRT_PLAN_TRANSPORT_GENERAL 0   /* kernels.hip k_transport                                                             */
 #define SOSRT_PLAN_TRANSPORT_FAST    1   /* transport_fast.hip (odd N, N > 256)                                                 */
 #define SOSRT_PLAN_TRANSPORT_RING    3   /* transport_ring.hip                                                                  */

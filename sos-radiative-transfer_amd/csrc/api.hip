@@ -158,6 +158,8 @@ struct sosrt_handle {
     double gemm_tail_frac = 0.6;         // ... and at or below this fraction of the group's columns (SOSRT_GEMM_TAIL_FRAC): above it the dense
                                          // tiling, skipping the tiles of converged columns, is the faster one (contraction -3 % per step at 512 ... 4096 columns)
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
+    int gemm_regs_cols = -1;             // at or below this many (symmetric form), 16-row tiles with the matrix fragments in registers
+                                         // (-1: while its workgroups, one per CU, are at most 1.5 rounds; 0: never -- SOSRT_GEMM_REGS)
     bool fast_ok = false;
     double* d_ratio = nullptr;
     int* h_pub = nullptr;                // pinned [groups][2 slots][4]: {live count, tag, needs k_smallmu, -} published from the device
@@ -357,7 +359,7 @@ int ensure_matrices(sosrt_handle* h, hipStream_t s) {
 // Jn for every row of a column group (grp < 0: the whole batch) in one launch: plain rows against W_atm, slab rows
 // against the combined matrix of their coefficient pair (or W_atm and W_aer in two passes)
 void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0,
-                int grp = -1, bool all_live = false) {
+                int grp = -1, bool all_live = false, bool regs_tile = false) {
     const int g0 = grp < 0 ? 0 : grp, g1 = grp < 0 ? h->ngroups : grp + 1;
     const int pg = grp < 0 ? 0 : grp;
     hipStream_t s = group_stream(h, pg);
@@ -425,7 +427,7 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
         ga.max_main = h->max_main; ga.max_slab = h->max_slab;
         ga.idx_up = h->nslab > 0 ? h->d_idx_up : nullptr; ga.idx_down = h->nslab > 0 ? h->d_idx_down : nullptr;
         ga.live_list = h->d_livelist + h->gb[g0]; ga.live_cap = tail_cols;
-        launch_gemm_tail(s, ga, tail_cols, tail_cols <= h->gemm_small_cols);
+        launch_gemm_tail(s, ga, tail_cols, tail_cols <= h->gemm_small_cols, regs_tile);
     } else {
         launch_gemm(s, ga);
     }
@@ -487,6 +489,18 @@ LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderIn
     pl.gemm = !live_tiling ? SOSRT_PLAN_GEMM_DENSE
                            : (pl.tail_cols <= h->gemm_small_cols ? ((use_sym(h) && pl.tail_cols <= 32) ? SOSRT_PLAN_GEMM_LIVE32_DEEP : SOSRT_PLAN_GEMM_LIVE32)
                                                                  : SOSRT_PLAN_GEMM_LIVE64);
+    // The last few columns: a tile's latency is the launch's, and the register-resident 16-row tile (jn_gemm_tile.hpp:
+    // gemm_tile_lone) has half the staged tile's -- a lone column's launch 12.6 -> 10.0 us at N = 128, 4.7 of which an empty launch
+    // takes (profiles/r04_gemm_regs_ab.txt).  Its workgroups are alone on their CUs and each fetches its own share of the matrix:
+    // it wins while they make at most about a round and a half (13 columns at L = 200, N = 128; 6 at N = 256), measured break-even
+    // at 16 / 8.  (Its tile's rows of In_1 must fit the LDS, and N rounded up to the k-chunk must be whole register blocks of 64.)
+    {
+        const int nct = (g.D + GEMM_BN - 1) / GEMM_BN;
+        const int auto_cap = (3 * h->cu_count / 2) / (((g.L + 15) / 16 + 1) * nct);
+        const int cap = h->gemm_regs_cols >= 0 ? h->gemm_regs_cols : (auto_cap > 1 ? auto_cap : 1);
+        if (live_tiling && use_sym(h) && pl.tail_cols <= cap && 16 * (g.D + 2) * 8 <= 150 * 1024 &&
+            ((g.N + GEMM_KC - 1) / GEMM_KC * GEMM_KC) % 64 == 0) pl.gemm = SOSRT_PLAN_GEMM_LIVE16_REGS;
+    }
     // transport
     {
         const int cols_now = pl.tail_cols > 0 ? pl.tail_cols : in.nb;
@@ -587,6 +601,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL_FRAC")) h->gemm_tail_frac = atof(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
+    if (const char* ev = getenv("SOSRT_GEMM_REGS")) h->gemm_regs_cols = atoi(ev);           // (A/B: 0 = the staged tilings for every live count)
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : (atoi(ev) == 1 ? 1 : 0);      // column groups of the order loop (0: auto)
     if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
 #ifdef SOSRT_DIAG   // measurement knobs of DESIGN section 5 (items 1, 5, 8): diagnostic builds only (-DSOSRT_DIAG), never in the product library
@@ -1526,7 +1541,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             n_max = n > n_max ? n : n_max;
             // this launch also publishes the group's live count after order n-1
             const int tail_cols = pl.tail_cols;
-            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb);
+            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb, pl.gemm == SOSRT_PLAN_GEMM_LIVE16_REGS);
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
                 prof_begin(h, SOSRT_K_SMALLMU, k);
                 launch_smallmu(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, h->d_desc + q.b0, q.cv.active);

@@ -176,9 +176,108 @@ __global__ __launch_bounds__(256, 2) void k_jn_gemm_tail_deep(GemmArgs g) {
     gemm_live_columns<TAIL_RT, true, true>(g, sA, sB);
 }
 
+// the last handful of columns (api.hip: plan_order, SOSRT_PLAN_GEMM_LIVE16_REGS): one tile's latency is the launch's, so the tile
+// keeps its share of the folded matrix in registers and has no barrier in its k-loop (jn_gemm_tile.hpp: gemm_tile_lone), and the
+// way to the tile is three memory round trips -- live flags; the column's slab rows and matrix group, requested together; operands
+// -- with the report to the host on a workgroup of its own (the last one: its release at system scope and the load in front of it
+// would otherwise be in front of the first tile).  Tile-major numbering as in gemm_live_columns, 16-row tiles for all rows.
+__global__ __launch_bounds__(256, 1) void k_jn_gemm_lone(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double s_lone[];
+    __shared__ int s_w[4];
+    __shared__ int s_col[4];                             // the tile's column, its first slab row, slab rows, matrix group
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == gridDim.x - 1) {
+        if (g.host_pub && tid == 0) publish_live_now(g);
+        return;
+    }
+    const int ts = (g.max_slab + 15) / 16, tm = (g.max_main + 15) / 16;
+    const int nct = (g.D + GEMM_BN - 1) / GEMM_BN;
+    const int id = blockIdx.x;
+    const int xq = (id / (8 * nct)) * 8 + (id & 7), bn0 = ((id >> 3) % nct) * GEMM_BN;
+    const int cap = g.live_cap > 0 ? g.live_cap : 1;
+    const int tq = xq / cap, ci = xq % cap;
+    if (tq >= ts + tm) return;                           // (uniform) padding of the grid
+    const int tt = tq < tm ? ts + tq : tq - tm;          // tt < ts: slab tile tt; else plain tile tt - ts (the short slab tiles last)
+    // The ci-th live column of the launch and, in the same round trip, what the tile needs to know of it: every thread looks at
+    // one candidate column's flag and descriptors.  The requests of the first 256 candidates leave before anything else ...
+    int fl = 0, iu_c = 0, id_c = -1, mg_c = 0;
+    if (tid < g.B) {
+        const int c = g.col0 + tid;
+        fl = g.active[c];
+        if (g.idx_up) {
+            iu_c = g.idx_up[c]; id_c = g.idx_down[c];
+            if (g.Wmix) mg_c = g.mix_group[c];
+        }
+    }
+    // ... and behind them, for a plain tile, the first two register blocks of its matrix: W_atm whatever the column
+    LoneFrag f0, f1;
+    const int nkb = (g.Ks >> 2) / LONE_KB;
+    if (tt >= ts) {
+        const int mcol = (bn0 >> 1) + (__builtin_amdgcn_readfirstlane(tid) >> 6) * 16 + (lane & 15);
+        const __amdgpu_buffer_rsrc_t rW = make_rsrc(g.Wa, g.Dp * g.Wld * 8);
+        lone_load(f0, rW, 0, lane >> 4, g.Wld, g.Wld >> 1, mcol);
+        if (nkb > 1) lone_load(f1, rW, 1, lane >> 4, g.Wld, g.Wld >> 1, mcol);
+    }
+    if (tid == 0) s_col[0] = -1;
+    int before = 0;
+    for (int base = 0;; base += 256) {
+        const bool f = fl != 0;
+        const unsigned long long mk = __ballot(f);
+        if (lane == 0) s_w[wave] = __popcll(mk);
+        __syncthreads();
+        int pre = before, tot = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) pre += s_w[w];
+            tot += s_w[w];
+        }
+        if (f && pre + __popcll(mk & ((2ull << lane) - 1)) == ci + 1) {
+            s_col[0] = g.col0 + base + tid; s_col[1] = iu_c; s_col[2] = id_c - iu_c + 1; s_col[3] = mg_c;
+        }
+        before += tot;
+        __syncthreads();
+        if (before > ci || base + 256 >= g.B) break;
+        fl = 0;                                          // the next 256 candidates (a group of more than 256 columns)
+        if (base + 256 + tid < g.B) {
+            const int c = g.col0 + base + 256 + tid;
+            fl = g.active[c];
+            if (g.idx_up) {
+                iu_c = g.idx_up[c]; id_c = g.idx_down[c];
+                if (g.Wmix) mg_c = g.mix_group[c];
+            }
+        }
+    }
+    const int b = s_col[0];
+    // the transport of this order takes its columns from this list
+    if (g.live_list && tq == 0 && bn0 == 0 && tid == 0 && ci < g.live_cap) g.live_list[ci] = b < 0 ? -1 : b - g.col0;
+    if (b < 0) return;                                   // fewer live columns than the host's (lagging) count
+    const int iu = g.idx_up ? s_col[1] : 0, ns = g.idx_up ? s_col[2] : 0, mg = s_col[3];
+    if (tt < ts) {
+        if (tt * 16 >= ns) return;
+        if (g.Wmix) gemm_tile_lone<false, false>(g, s_lone, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true}, f0, f1, g.Wmix + (size_t)mg * g.Dp * g.Wld);
+        else gemm_tile_lone<true, false>(g, s_lone, tt, bn0, ColumnRows{b * g.L, iu, ns, ns, true}, f0, f1);
+    } else {
+        if ((tt - ts) * 16 >= g.L - ns) return;
+        gemm_tile_lone<false, true>(g, s_lone, tt - ts, bn0, ColumnRows{b * g.L, iu, ns, g.L - ns, false}, f0, f1);
+    }
+}
+
 }  // namespace
 
-void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles) {
+void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles, bool regs) {
+    if (regs && a.sym) {
+        const int ts = (a.max_slab + 15) / 16, tm = (a.max_main + 15) / 16;
+        if (cols <= 0 || ts + tm <= 0) return;
+        const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
+        const int lds = 16 * (a.D + 2) * 8;
+        static bool big_lds = false;                     // (more than 64 KB of dynamic LDS from N = 256 on)
+        if (!big_lds) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_jn_gemm_lone), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            big_lds = true;
+        }
+        // (+ 1: the workgroup that reports to the host)
+        hipLaunchKernelGGL(k_jn_gemm_lone, dim3((unsigned)((cols * (ts + tm) + 7) / 8 * 8 * nct + 1)), dim3(256), (size_t)lds, s, a);
+        return;
+    }
     const int rt = small_tiles ? TAIL_RT : GEMM_RT;
     const int ts = (a.max_slab + 16 * TAIL_RT_SLAB - 1) / (16 * TAIL_RT_SLAB);
     const int tm = (a.max_main + 16 * rt - 1) / (16 * rt);

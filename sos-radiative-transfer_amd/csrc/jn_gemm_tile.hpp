@@ -311,6 +311,114 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, double* sA, double*
 }
 
 
+// The tile of the LAST FEW live columns (symmetric form): 16 rows x 64 values of m, no barrier inside the k-loop.
+//
+// A launch over a handful of columns is one tile's latency, and the staged tile above is eight k-chunks that wait for each other
+// (two barriers, an LDS round trip, 16 MFMAs: ~1 us a chunk -- profiles/r04_order_loop_timeline.txt).  With a workgroup alone on
+// its CU the register file holds what the chunks were staged for: a lane's fragments of the folded matrix for a block of 64 values
+// of k are 2 x 16 doubles, requested straight from L2 into registers, two blocks in flight in two register sets; the tile's 16 rows
+// of In_1 come into LDS whole by LDS-DMA (one barrier) and a lane forms u = c (a + b), v = c (a - b) on its way into the MFMA.
+// Same products, same order of k, same epilogue as gemm_tile<.., SYM> -- a row's bits do not depend on the tiling that computed it.
+// SLAB: two passes (W_atm with ca, then W_aer with cr) for slab rows without a combined matrix; wmix: one pass, unit coefficient.
+constexpr int LONE_KB = 16;         // k-steps (of 4) per register block
+struct LoneFrag { double s[LONE_KB], a[LONE_KB]; };      // a lane's fragments of [S | A] for one block of 64 values of k
+// block `kb` (of the pass's Ks / 64) of the folded matrix W: k = 64 kb + 4 q + (lane >> 4), columns m (of S) and Nh + m (of A).
+// Buffer loads: the lane's part of the address is two registers for all 32 requests (the k-step goes into the scalar offset);
+// with 64-bit addresses the 8-KB stride between k-steps costs a register pair per request and the fragments spill.
+__device__ __forceinline__ void lone_load(LoneFrag& F, __amdgpu_buffer_rsrc_t rW, int kb, int fk, int Wld, int Nh, int mcol) {
+    const int vs = (fk * Wld + mcol) * 8, va = vs + Nh * 8;
+#pragma unroll
+    for (int q = 0; q < LONE_KB; ++q) {
+        const int so = 4 * (kb * LONE_KB + q) * Wld * 8;
+        F.s[q] = bload(rW, vs, so);
+        F.a[q] = bload(rW, va, so);
+    }
+}
+// PRELOADED: the caller requested blocks 0 and 1 of the (single) pass into f0 / f1 before it knew the tile's column -- the plain
+// rows' matrix is the same for every column, so its fragments travel while the live flags do.
+template <bool SLAB, bool PRELOADED>
+__device__ __forceinline__ void gemm_tile_lone(const GemmArgs& g, double* sRaw, int tile, int bn0, ColumnRows row_of,
+                                               LoneFrag& f0, LoneFrag& f1, const double* __restrict__ wmix = nullptr) {
+    static_assert(!(SLAB && PRELOADED), "two passes start from the column's own coefficients");
+    typedef __attribute__((address_space(3))) void* lds_ptr_t_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int D = g.D, Wld = g.Wld, Nn = D >> 1, Nh = Wld >> 1;
+    const int RS = D + 2;                                // row stride of sRaw: 16-byte aligned rows, 4 banks apart (D = 0 mod 32)
+    const int fr = lane & 15, fk = lane >> 4;
+    const int nkb = (g.Ks >> 2) / LONE_KB;               // register blocks per pass (the host takes this tile when Ks is a multiple of 64)
+    const int nblk = (SLAB ? 2 : 1) * nkb;
+    const int grow = row_of(tile * 16 + fr);             // the row whose A fragment this lane supplies
+    const double cf_a = grow >= 0 ? (wmix ? 1.0 : g.ca[grow]) : 0.0;
+    const double cf_r = (SLAB && grow >= 0) ? g.cr[grow] : 0.0;
+    // the tile's rows of In_1, whole, by LDS-DMA (a wave takes every fourth row)
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A + (size_t)row_of.base * D, g.L * D * 8);
+    const int rowbytes = D * 8, pieces = (rowbytes + 1023) / 1024;
+    for (int r = wave; r < 16; r += 4) {
+        const int gr_ = row_of(tile * 16 + r);
+        if (gr_ < 0) continue;                           // (uniform) padding row: never read below
+        const int ro = (gr_ - row_of.base) * rowbytes;
+        for (int pc = 0; pc < pieces; ++pc)
+            if (pc * 1024 + lane * 16 < rowbytes)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t_)(sRaw + (size_t)r * RS + pc * 128), 16, lane * 16, ro + pc * 1024, 0, 0);
+    }
+    // this lane's fragments of the folded matrix: X against S (first half of a row of [S | A]), Y against A
+    const int mcol = (bn0 >> 1) + wave * 16 + fr;
+#define SOSRT_LONE_LOAD(F, blk_)                                                                                  \
+    {                                                                                                             \
+        const int b_ = (blk_);                                                                                    \
+        if (b_ < nblk) {                                                                                          \
+            const int pass_ = b_ >= nkb ? 1 : 0;                                                                  \
+            lone_load(F, pass_ ? rW1 : rW0, b_ - pass_ * nkb, fk, Wld, Nh, mcol);                                 \
+        }                                                                                                         \
+    }
+    const __amdgpu_buffer_rsrc_t rW0 = make_rsrc(wmix ? wmix : g.Wa, g.Dp * Wld * 8);
+    const __amdgpu_buffer_rsrc_t rW1 = make_rsrc(SLAB ? g.Wr : g.Wa, g.Dp * Wld * 8);
+    if (!PRELOADED) {
+        SOSRT_LONE_LOAD(f0, 0);
+        SOSRT_LONE_LOAD(f1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f64x4 accx = (f64x4){0, 0, 0, 0}, accy = (f64x4){0, 0, 0, 0};
+    const double* __restrict__ arow = sRaw + (size_t)fr * RS;
+#define SOSRT_LONE_COMPUTE(F, blk_)                                                                               \
+    {                                                                                                             \
+        const int b_ = (blk_);                                                                                    \
+        const int pass_ = b_ >= nkb ? 1 : 0;                                                                      \
+        const double cf_ = pass_ ? cf_r : cf_a;                                                                   \
+        const int k0_ = 4 * (b_ - pass_ * nkb) * LONE_KB + fk;                                                    \
+        _Pragma("unroll") for (int q = 0; q < LONE_KB; ++q) {                                                     \
+            const int k_ = k0_ + 4 * q;                                                                           \
+            const bool ok_ = grow >= 0 && k_ < Nn;                                                                \
+            const double a_ = arow[k_], m_ = arow[D - 1 - k_];          /* (in bounds whatever k_ < Ks) */        \
+            const double u_ = ok_ ? cf_ * (a_ + m_) : 0.0, v_ = ok_ ? cf_ * (a_ - m_) : 0.0;                      \
+            accx = __builtin_amdgcn_mfma_f64_16x16x4f64(u_, F.s[q], accx, 0, 0, 0);                               \
+            accy = __builtin_amdgcn_mfma_f64_16x16x4f64(v_, F.a[q], accy, 0, 0, 0);                               \
+        }                                                                                                         \
+    }
+    for (int blk = 0; blk < nblk; blk += 2) {
+        SOSRT_LONE_COMPUTE(f0, blk);
+        SOSRT_LONE_LOAD(f0, blk + 2);
+        if (blk + 1 < nblk) {
+            SOSRT_LONE_COMPUTE(f1, blk + 1);
+            SOSRT_LONE_LOAD(f1, blk + 3);
+        }
+    }
+#undef SOSRT_LONE_LOAD
+#undef SOSRT_LONE_COMPUTE
+    // epilogue: lane holds m = mcol, rows 4r + (l >> 4)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gr = row_of(tile * 16 + 4 * r + fk);
+        if (gr >= 0 && mcol < Nn) {
+            const double x = accx[r], y = accy[r];
+            g.C[(size_t)gr * D + mcol] = x + y;
+            g.C[(size_t)gr * D + D - 1 - mcol] = x - y;
+        }
+    }
+}
+
 constexpr int TAIL_RT_SLAB = 1;     // MFMA row tiles of the live-column tilings: slab rows (16-row tiles)
 constexpr int TAIL_RT = 2;          // ... plain rows of the small tiling (32-row tiles)
 

@@ -206,14 +206,16 @@ struct GemmArgs {
     int check_tiles = 1;             // dense kernel: skip the tiles whose columns have all converged (two barriers and a dependent load per tile)
 };
 
+// (publish_live_now: by the calling thread, whichever workgroup it belongs to)
+__device__ inline void publish_live_now(const GemmArgs& g) {
+    const int live = __hip_atomic_load(g.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int* slot = g.host_pub + 4 * (g.tag & 1);
+    __hip_atomic_store(slot, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 2, g.need_small ? g.need_small[0] : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 1, g.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ inline void publish_live(const GemmArgs& g) {
-    if (g.host_pub && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        const int live = __hip_atomic_load(g.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int* slot = g.host_pub + 4 * (g.tag & 1);
-        __hip_atomic_store(slot, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(slot + 2, g.need_small ? g.need_small[0] : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(slot + 1, g.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (g.host_pub && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) publish_live_now(g);
 }
 void launch_gemm(hipStream_t s, const GemmArgs& a);
 struct OrderLoopArgs {
@@ -246,7 +248,7 @@ void launch_wmix(hipStream_t s, size_t n, int ngroups, const double* Wa, const d
 void launch_symfold(hipStream_t s, int nmat, int N, int D, int Dp, int Wld, const double* W, double* SA);
 // some columns have converged (at most `cols` are live, an upper bound): workgroups only for live
 // columns; small_tiles: 32-row tiles and deeper staging for the last few
-void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles);
+void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_tiles, bool regs = false);
 void launch_smallmu(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In,
                     const ColDesc* desc, const int* active);
 void launch_transport(hipStream_t s, const Grid& g, int B, const double* tau, const double* Jn, double* In, double* I,

@@ -15,7 +15,7 @@ COL_OK, COL_INDEXERROR, COL_MAXORDERS, COL_INTERNAL = 0, 1, 2, 3
 GEOM_THREE_ZONE, GEOM_SINGLE_SLAB = 0, 1
 SURFACE_NONE, SURFACE_SPECULAR, SURFACE_LAMBERTIAN, SURFACE_LAMBERTIAN_README = 0, 1, 2, 3
 K_GEMM, K_TRANSPORT, K_FIRST, K_SMALLMU, K_ORDER_LOOP = 0, 1, 2, 3, 4
-PLAN_GEMM_DENSE, PLAN_GEMM_LIVE64, PLAN_GEMM_LIVE32, PLAN_GEMM_LIVE32_DEEP = 0, 1, 2, 3
+PLAN_GEMM_DENSE, PLAN_GEMM_LIVE64, PLAN_GEMM_LIVE32, PLAN_GEMM_LIVE32_DEEP, PLAN_GEMM_LIVE16_REGS = 0, 1, 2, 3, 4
 PLAN_TRANSPORT_GENERAL, PLAN_TRANSPORT_FAST, PLAN_TRANSPORT_RING, PLAN_TRANSPORT_SCAN = 0, 1, 3, 4
 CONTRACT_F64, CONTRACT_F32, CONTRACT_F64_FULL = 0, 1, 2
 FIRST_ORDER_CODED, FIRST_ORDER_README = 0, 1

@@ -470,6 +470,44 @@ def test_order_loop_kernel_keeps_the_bits(L, N, B, surface, monkeypatch):
     assert np.array_equal(a.I, b.I)                                            # bit for bit
 
 
+@pytest.mark.parametrize("L,N,B,surface,pairs", [(200, 128, 1, "specular", 1), (200, 128, 9, "specular", 3), (200, 256, 3, "specular", 2),
+                                                  (72, 64, 5, "lambertian", 2), (40, 64, 48, "specular", 48), (24, 128, 300, "specular", 4),
+                                                  (35, 192, 4, "specular", 2)])
+def test_register_resident_contraction_tile_keeps_the_bits(L, N, B, surface, pairs, monkeypatch):
+    """The contraction of the last few live columns (csrc/jn_gemm_tile.hpp: gemm_tile_lone -- 16-row tiles, a lane's fragments of the
+    folded matrix in registers, no barrier in the k-loop; api.hip: SOSRT_PLAN_GEMM_LIVE16_REGS) against the staged live-column
+    tilings (SOSRT_GEMM_REGS=0): same order counts, same statuses, the same bits -- a lone column, several columns, N = 256 (more
+    than 64 KB of LDS), a Lambertian surface, more slab coefficient pairs than combined matrices (two passes), a group of more than
+    256 columns (two rounds of candidates in the search for the tile's column) and a shape whose last tiles are ragged."""
+    from sosrt import main as M
+    rng = np.random.default_rng(100 * L + N + B)
+    mu0 = rng.uniform(0.2, 1.0, B)
+    taer = np.geomspace(0.02, 1.2, pairs)[rng.integers(0, pairs, B)]
+    rho = rng.uniform(0.0, 0.8, B)
+    walb = np.linspace(0.85, 1.0, pairs)[rng.integers(0, pairs, B)] if pairs > 32 else 0.95
+    if pairs > 32:
+        taer = np.geomspace(0.02, 1.5, B)
+    kw = dict(tauStar_atm=0.124, alb_aer=walb, nb_layers=L, nb_angles=N, max_orders=200, surface=surface, raise_on_error=False)
+    out = {}
+    for regs in ("0", "64"):
+        monkeypatch.setenv("SOSRT_GEMM_REGS", regs)
+        monkeypatch.setenv("SOSRT_GROUPS", "1")
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+        out[regs] = SOS_Aer_batch(mu0, taer, rho, **kw)
+        plans = [s_.plan_launch(B, min(B, 2), surface=surface) for s_ in M._solvers.values()]
+        assert plans and plans[0]["gemm"] == (_lib.PLAN_GEMM_LIVE16_REGS if regs == "64" else _lib.PLAN_GEMM_LIVE32_DEEP), plans
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    a, b = out["0"], out["64"]
+    assert np.array_equal(a.n, b.n), (a.n, b.n)
+    assert np.array_equal(a.status, b.status)
+    assert (a.status == 0).any()
+    assert np.array_equal(a.I, b.I)                                            # bit for bit
+
+
 def test_a_refused_order_loop_launch_hands_the_orders_back():
     """The residency handshake of an order-loop launch, made to fail on purpose (mode 2: a grid of twice the device's CUs): every
     workgroup that is on the machine waits 4 ms for the ones that are not, one of them declares the launch NOT RESIDENT, nothing
