@@ -158,6 +158,7 @@ struct sosrt_handle {
     double gemm_tail_frac = 0.6;         // ... and at or below this fraction of the group's columns (SOSRT_GEMM_TAIL_FRAC): above it the dense
                                          // tiling, skipping the tiles of converged columns, is the faster one (contraction -3 % per step at 512 ... 4096 columns)
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
+    int dense_live_list = 1;             // the dense tiling writes the transport's live list (SOSRT_DENSE_LIVE_LIST=0: A/B)
     int gemm_regs_cols = -1;             // at or below this many (symmetric form), 16-row tiles with the matrix fragments in registers
                                          // (-1: while its workgroups, one per CU, are at most 1.5 rounds; 0: never -- SOSRT_GEMM_REGS)
     bool fast_ok = false;
@@ -359,7 +360,7 @@ int ensure_matrices(sosrt_handle* h, hipStream_t s) {
 // Jn for every row of a column group (grp < 0: the whole batch) in one launch: plain rows against W_atm, slab rows
 // against the combined matrix of their coefficient pair (or W_atm and W_aer in two passes)
 void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* active, int tail_cols = 0, int pub_tag = 0,
-                int grp = -1, bool all_live = false, bool regs_tile = false) {
+                int grp = -1, bool all_live = false, bool regs_tile = false, int dense_live_cap = 0) {
     const int g0 = grp < 0 ? 0 : grp, g1 = grp < 0 ? h->ngroups : grp + 1;
     const int pg = grp < 0 ? 0 : grp;
     hipStream_t s = group_stream(h, pg);
@@ -429,6 +430,10 @@ void run_source(sosrt_handle* h, const double* In_1, double* Jn, const int* acti
         ga.live_list = h->d_livelist + h->gb[g0]; ga.live_cap = tail_cols;
         launch_gemm_tail(s, ga, tail_cols, tail_cols <= h->gemm_small_cols, regs_tile);
     } else {
+        if (dense_live_cap > 0 && active && h->nslab >= 0) {     // the dense tiling writes the transport's live list too
+            ga.col0 = h->nslab > 0 ? h->gb[g0] : 0; ga.B = h->gb[g1] - h->gb[g0];
+            ga.live_list = h->d_livelist + h->gb[g0]; ga.live_cap = dense_live_cap;
+        }
         launch_gemm(s, ga);
     }
     prof_end(h, SOSRT_K_GEMM, pg);
@@ -468,6 +473,7 @@ struct OrderInputs {                     // what the plan of one order depends o
 };
 struct LaunchPlan {
     int tail_cols = 0;                   // contraction over the live columns: capacity of the launch (0: dense tiling over the row lists)
+    int live_cap = 0;                    // transport over the live list: its capacity (0: over all columns of the group)
     int gemm = SOSRT_PLAN_GEMM_DENSE;
     int transport = SOSRT_PLAN_TRANSPORT_GENERAL;
     int parts = 1;                       // chunk-parallel kernel: workgroups per column
@@ -501,9 +507,13 @@ LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderIn
         if (live_tiling && use_sym(h) && pl.tail_cols <= cap && 16 * (g.D + 2) * 8 <= 150 * 1024 &&
             ((g.N + GEMM_KC - 1) / GEMM_KC * GEMM_KC) % 64 == 0) pl.gemm = SOSRT_PLAN_GEMM_LIVE16_REGS;
     }
+    // The transport takes its columns from the live list whenever some column has converged: the live-column tilings write the
+    // list, and so does the dense tiling (one more workgroup) -- the ring-class kernels then run over the live columns, dealt to
+    // the CUs one by one, instead of over a batch whose live columns sit where they were put.  (Not the float contraction.)
+    pl.live_cap = live_tiling ? pl.tail_cols : ((h->contraction != SOSRT_CONTRACT_F32 && h->dense_live_list && in.known < in.nb) ? in.known : 0);
     // transport
     {
-        const int cols_now = pl.tail_cols > 0 ? pl.tail_cols : in.nb;
+        const int cols_now = pl.live_cap > 0 ? pl.live_cap : in.nb;
         // chunk-parallel kernel: a column on ceil(N / 64) CUs (two at N = 128, four at N = 256) while that many workgroups per
         // live column fit the device at once (the reflection must stay inside a part)
         // (where the shape has no ring kernel -- odd N, N > 256: the split form's WIDE instantiation -- the alternative is the
@@ -601,6 +611,7 @@ int sosrt_create(int device, int L, int N, int max_batch, int max_orders, sosrt_
     if (const char* ev = getenv("SOSRT_GEMM_TAIL")) h->gemm_tail_cols = atoi(ev);
     if (const char* ev = getenv("SOSRT_GEMM_TAIL_FRAC")) h->gemm_tail_frac = atof(ev);
     if (const char* ev = getenv("SOSRT_GEMM_SMALL")) h->gemm_small_cols = atoi(ev);
+    if (const char* ev = getenv("SOSRT_DENSE_LIVE_LIST")) h->dense_live_list = atoi(ev) != 0;
     if (const char* ev = getenv("SOSRT_GEMM_REGS")) h->gemm_regs_cols = atoi(ev);           // (A/B: 0 = the staged tilings for every live count)
     if (const char* ev = getenv("SOSRT_GROUPS")) h->want_groups = atoi(ev) >= 2 ? 2 : (atoi(ev) == 1 ? 1 : 0);      // column groups of the order loop (0: auto)
     if (const char* ev = getenv("SOSRT_SPLIT_MIN")) h->split_min = atoi(ev);                  // smallest batch that is split
@@ -1541,7 +1552,8 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
             n_max = n > n_max ? n : n_max;
             // this launch also publishes the group's live count after order n-1
             const int tail_cols = pl.tail_cols;
-            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb, pl.gemm == SOSRT_PLAN_GEMM_LIVE16_REGS);
+            run_source(h, q.In_1, h->d_Jn, h->d_active, tail_cols, tagbase + n - 1, k, q.known == q.nb, pl.gemm == SOSRT_PLAN_GEMM_LIVE16_REGS,
+                       tail_cols > 0 ? 0 : pl.live_cap);
             if (g.nsmall > 0 && h->need_small) {      // skipped once the device has reported that every such lane is rewritten anyway
                 prof_begin(h, SOSRT_K_SMALLMU, k);
                 launch_smallmu(sg, g, q.nb, tau_g, h->d_Jn + fo, q.In + fo, h->d_desc + q.b0, q.cv.active);
@@ -1555,7 +1567,7 @@ int sosrt_solve_dev(sosrt_t* h, int B, const double* d_tau, const double* d_P0_a
                 Grid gt = g;
                 if (pl.transport >= SOSRT_PLAN_TRANSPORT_RING && !h->need_small) gt.nsmall = 0;
                 launch_transport(sg, gt, q.nb, tau_g, h->d_Jn + fo, q.In + fo, d_I_out + fo, sv_n, saved_stride, h->d_desc + q.b0, q.cv, n, 1,
-                                 h->d_E, pl.transport, erep_g, tail_cols, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0,
+                                 h->d_E, pl.transport, erep_g, pl.live_cap, h->d_livelist + q.b0, NG > 1 ? h->coresident_slots : 0,
                                  pl.parts > 1 ? 1 : 0, h->d_scan_scratch + (size_t)q.b0 * transport_scan_scratch_doubles(),
                                  h->d_scan_sync + 2 * q.b0, nzcap);
                 if (pl.repair)                           // register-streaming kernel: a search that leaves wave 0 is redone by the

@@ -46,8 +46,39 @@ constexpr int DENSE_SLAB_RT = SOSRT_DENSE_SLAB_RT;
 #endif
 constexpr int DENSE_SLAB_ROWS = 16 * DENSE_SLAB_RT;
 
+// The live columns of the launch's group, in ascending order, for the transport of this order (live_list[i] = i-th live column
+// relative to col0, -1 from the live count up to live_cap): one workgroup.  The live-column tilings write the list as they find
+// their columns; the dense tiling has no such step, and a transport launched over ALL columns of a half-converged batch leaves
+// its live columns where the batch put them -- two to a CU here, none there: 124 us for 271 live columns of 512 where the same
+// kernel over the list takes 75 (profiles/r04_order_table.txt, orders 11-13).
+__device__ __forceinline__ void write_live_list(const GemmArgs& g) {
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int before = 0;
+    for (int base = 0; base < g.B; base += 256) {
+        const bool f = base + tid < g.B && g.active[g.col0 + base + tid] != 0;
+        const unsigned long long mk = __ballot(f);
+        if (lane == 0) s_cnt[wave] = __popcll(mk);
+        __syncthreads();
+        int pre = before, tot = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) pre += s_cnt[w];
+            tot += s_cnt[w];
+        }
+        const int at = pre + __popcll(mk & ((1ull << lane) - 1));
+        if (f && at < g.live_cap) g.live_list[at] = base + tid;
+        before += tot;
+        __syncthreads();
+    }
+    for (int i = before + tid; i < g.live_cap; i += 256) g.live_list[i] = -1;
+}
+
 template <bool SYM>
 __global__ __launch_bounds__(256, GEMM_WPS) void k_jn_gemm(GemmArgs g) {
+    if (g.live_list && blockIdx.x == gridDim.x - 1) {    // (the launch's extra workgroup: launch_gemm)
+        write_live_list(g);
+        return;
+    }
     publish_live(g);
     __shared__ double sA[(SYM ? 2 : 1) * 16 * (GEMM_RT > 2 ? GEMM_RT : 2) * A_LD];
     __shared__ double sB[GEMM_KC * B_LD];
@@ -311,7 +342,8 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     const int tiles = (a.n_main + 16 * GEMM_RT - 1) / (16 * GEMM_RT) + (a.n_slab + DENSE_SLAB_ROWS - 1) / DENSE_SLAB_ROWS;
     if (tiles <= 0) return;
     const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
-    dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nct));
+    // (+ 1 with a live list: the workgroup that writes it)
+    dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nct + (a.live_list ? 1 : 0)));
     if (a.sym) hipLaunchKernelGGL(k_jn_gemm<true>, grid, dim3(256), (size_t)a.pad_lds, s, a);
     else hipLaunchKernelGGL(k_jn_gemm<false>, grid, dim3(256), (size_t)a.pad_lds, s, a);
 }

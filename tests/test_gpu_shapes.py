@@ -508,6 +508,38 @@ def test_register_resident_contraction_tile_keeps_the_bits(L, N, B, surface, pai
     assert np.array_equal(a.I, b.I)                                            # bit for bit
 
 
+@pytest.mark.parametrize("case", ["three_zones", "two_layers", "two_groups"])
+def test_transport_over_the_dense_tilings_live_list_keeps_the_bits(case, monkeypatch):
+    """While most columns of a group are live the contraction keeps its dense tiling, whose extra workgroup writes the live list
+    (csrc/jn_gemm.hip: write_live_list), and the ring-class transport runs over that list -- its kernel chosen by the live count --
+    instead of over every column of the group; columns of more than three zones, which have the dense tiling only, get their tail
+    onto the chunk-parallel kernel that way.  Same order counts, statuses and bits as with SOSRT_DENSE_LIVE_LIST=0."""
+    from sosrt import main as M
+    from sosrt.main import SOS_Aer_layers
+    rng = np.random.default_rng(5)
+    B, L, N = (300, 40, 128) if case != "two_layers" else (90, 48, 128)
+    mu0 = rng.uniform(0.2, 1.0, B); rho = rng.uniform(0.0, 0.8, B)
+    taer = rng.choice([0.02, 0.12, 0.6, 1.0], B)
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("SOSRT_DENSE_LIVE_LIST", on)
+        monkeypatch.setenv("SOSRT_GROUPS", "2" if case == "two_groups" else "1")
+        for s_ in list(M._solvers.values()):
+            s_.close()
+        M._solvers.clear()
+        if case == "two_layers":
+            out[on] = SOS_Aer_layers(mu0, rho, [(60, 50, 0.2, 0.90), (25, 17, 0.4, 0.97)], nb_layers=L, nb_angles=N, max_orders=200, raise_on_error=False)
+        else:
+            out[on] = SOS_Aer_batch(mu0, taer, rho, tauStar_atm=0.124, alb_aer=0.95, nb_layers=L, nb_angles=N, max_orders=200, raise_on_error=False)
+    for s_ in list(M._solvers.values()):
+        s_.close()
+    M._solvers.clear()
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status) and (a.status == 0).any()
+    assert a.n.max() > a.n.min() + 3                                           # the columns do leave one by one
+    assert np.array_equal(a.I, b.I)                                            # bit for bit
+
+
 def test_a_refused_order_loop_launch_hands_the_orders_back():
     """The residency handshake of an order-loop launch, made to fail on purpose (mode 2: a grid of twice the device's CUs): every
     workgroup that is on the machine waits 4 ms for the ones that are not, one of them declares the launch NOT RESIDENT, nothing

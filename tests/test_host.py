@@ -196,8 +196,10 @@ def test_launch_plan_of_the_order_loop():
     # BASELINE C4 shape (L = 200, N = 128), the 512-column sweep: two column groups of 256
     p = plan(128, 200, 512, 512)
     assert (p["groups"], p["gemm"], p["transport"], p["order_loop"]) == (2, G.PLAN_GEMM_DENSE, T.PLAN_TRANSPORT_RING, 0)
-    p = plan(128, 200, 512, 180)                    # a few converged (more than 60 % of the group live): the dense tiling skips their tiles
+    p = plan(128, 200, 512, 230)                    # a few converged (more than 60 % of the group live): the dense tiling skips their tiles
     assert (p["gemm"], p["tail_cols"], p["transport"]) == (G.PLAN_GEMM_DENSE, 0, T.PLAN_TRANSPORT_RING)
+    p = plan(128, 200, 512, 180)                    # ... and writes the live list: the transport's choice follows the live count, not the group's size
+    assert (p["gemm"], p["tail_cols"], p["transport"], p["parts"]) == (G.PLAN_GEMM_DENSE, 0, T.PLAN_TRANSPORT_SCAN, 1)
     p = plan(128, 200, 512, 150)                    # contraction over the live columns, chunk-parallel transport
     assert (p["gemm"], p["tail_cols"], p["transport"], p["parts"], p["order_loop"]) == (G.PLAN_GEMM_LIVE32, 150, T.PLAN_TRANSPORT_SCAN, 1, 0)
     p = plan(128, 200, 512, 100)                    # two workgroups per column while they fit the CUs
