@@ -300,10 +300,9 @@ void launch_gemm_tail(hipStream_t s, const GemmArgs& a, int cols, bool small_til
         if (cols <= 0 || ts + tm <= 0) return;
         const int nct = (a.D + GEMM_BN - 1) / GEMM_BN;
         const int lds = 16 * (a.D + 2) * 8;
-        static bool big_lds = false;                     // (more than 64 KB of dynamic LDS from N = 256 on)
-        if (!big_lds) {
+        static PerDeviceOnce big_lds;                           // (more than 64 KB of dynamic LDS from N = 256 on)
+        if (big_lds.first()) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_jn_gemm_lone), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            big_lds = true;
         }
         // (+ 1: the workgroup that reports to the host)
         hipLaunchKernelGGL(k_jn_gemm_lone, dim3((unsigned)((cols * (ts + tm) + 7) / 8 * 8 * nct + 1)), dim3(256), (size_t)lds, s, a);

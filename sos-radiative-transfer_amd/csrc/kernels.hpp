@@ -217,6 +217,18 @@ __device__ inline void publish_live_now(const GemmArgs& g) {
 __device__ inline void publish_live(const GemmArgs& g) {
     if (g.host_pub && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) publish_live_now(g);
 }
+// A kernel's opt-in to more than 64 KB of dynamic LDS (hipFuncSetAttribute) is made once per DEVICE: a process may hold handles on
+// several GPUs (sosrt_create(device = k)), and the attribute set under one device does not reach the kernel's object on another.
+struct PerDeviceOnce {
+    bool seen[64] = {};
+    bool first() {                                   // true the first time the current device asks
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (seen[d]) return false;
+        seen[d] = true;
+        return true;
+    }
+};
 void launch_gemm(hipStream_t s, const GemmArgs& a);
 struct OrderLoopArgs {
     TransportArgs t;           // the column group's view (every per-column pointer offset to its first column): g, tau, Jn, I, desc, cv, Etab, erep, scan_scratch, scan_sync

@@ -245,11 +245,10 @@ size_t order_loop_raw_lds(const Grid& g) { return (size_t)16 * TAIL_RT * (g.D + 
 template <bool SPLIT, int NC>
 hipError_t launch_order_loop_t(hipStream_t s, int grid, const OrderLoopArgs& p) {
     auto kern = k_order_loop<SPLIT, NC>;
-    static bool big_lds = false;
-    if (!big_lds) {
+    static PerDeviceOnce big_lds;      
+    if (big_lds.first()) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBytes);
         if (e != hipSuccess) return e;
-        big_lds = true;
     }
     size_t shm = scan_lds_bytes<SPLIT>(p.t.g, kRingZones);
     if (shm < order_loop_gemm_lds()) shm = order_loop_gemm_lds();

@@ -655,11 +655,10 @@ void launch_p(hipStream_t s, dim3 grid, dim3 block, const TransportArgs& a, int 
 #define SOSRT_RING_LAUNCH_Z(ACC_, SAVED_, MZ_)                                                                 \
     do {                                                                                                       \
         auto kern = k_transport_ring<ACC_, SAVED_, PIECES, MZ_>;                                               \
-        static bool big_lds = false;                                                                           \
-        if (!big_lds) {                                                                                        \
+        static PerDeviceOnce big_lds;                                                                                 \
+        if (big_lds.first()) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)kRingLdsBytes);                                                                   \
-            big_lds = true;                                                                                    \
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, NS, g_ring_debug, ring_fixcap(a.g));                           \
     } while (0)

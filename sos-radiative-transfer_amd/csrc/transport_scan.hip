@@ -32,11 +32,10 @@ void launch_scan_wide(hipStream_t s, dim3 grid, const TransportArgs& a) {
 #define SOSRT_SCAN_LAUNCH_W(SAVED_, MZ_)                                                                       \
     do {                                                                                                       \
         auto kern = k_transport_scan<true, SAVED_, true, 0, MZ_, true>;                                        \
-        static bool big_lds = false;                                                                           \
-        if (!big_lds) {                                                                                        \
+        static PerDeviceOnce big_lds;                                                                                 \
+        if (big_lds.first()) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)kScanLdsBytes);                                                           \
-            big_lds = true;                                                                                    \
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
     } while (0)
@@ -57,11 +56,10 @@ void launch_scan_t(hipStream_t s, dim3 grid, const TransportArgs& a) {
 #define SOSRT_SCAN_LAUNCH_Z(ACC_, SAVED_, NC_, MZ_)                                                            \
     do {                                                                                                       \
         auto kern = k_transport_scan<ACC_, SAVED_, SPLIT, NC_, MZ_>;                                           \
-        static bool big_lds = false;                                                                           \
-        if (!big_lds) {                                                                                        \
+        static PerDeviceOnce big_lds;                                                                                 \
+        if (big_lds.first()) {                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)kScanLdsBytes);                                                           \
-            big_lds = true;                                                                                    \
         }                                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, shm, s, a, scan_fixcap(a.g));                                    \
     } while (0)
