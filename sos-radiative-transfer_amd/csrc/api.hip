@@ -160,7 +160,7 @@ struct sosrt_handle {
     int gemm_small_cols = 200;           // at or below this many, 32-row tiles (SOSRT_GEMM_SMALL)
     int dense_live_list = 1;             // the dense tiling writes the transport's live list (SOSRT_DENSE_LIVE_LIST=0: A/B)
     int gemm_regs_cols = -1;             // at or below this many (symmetric form), 16-row tiles with the matrix fragments in registers
-                                         // (-1: while its workgroups, one per CU, are at most 1.5 rounds; 0: never -- SOSRT_GEMM_REGS)
+                                         // (-1: while its workgroups, one per CU, are at most 1.5 rounds of the CUs; 0: never -- SOSRT_GEMM_REGS)
     bool fast_ok = false;
     double* d_ratio = nullptr;
     int* h_pub = nullptr;                // pinned [groups][2 slots][4]: {live count, tag, needs k_smallmu, -} published from the device
@@ -499,11 +499,11 @@ LaunchPlan plan_order(const sosrt_handle* h, const SolveShape& sh, const OrderIn
     // gemm_tile_lone) has half the staged tile's -- a lone column's launch 12.6 -> 10.0 us at N = 128, 4.7 of which an empty launch
     // takes (profiles/r04_gemm_regs_ab.txt).  Its workgroups are alone on their CUs and each fetches its own share of the matrix:
     // it wins while they make at most about a round and a half (13 columns at L = 200, N = 128; 6 at N = 256), measured break-even
-    // at 16 / 8.  (Its tile's rows of In_1 must fit the LDS, and N rounded up to the k-chunk must be whole register blocks of 64.)
+    // at 16 / 8 -- and loses where a lone column is already more than that: L = 800, N = 501, 133 -> 144 us per order (profiles/r04_gemm_regs_ab.txt).  (Its tile's rows of In_1 must fit the LDS, and N rounded up to the k-chunk must be whole register blocks of 64.)
     {
         const int nct = (g.D + GEMM_BN - 1) / GEMM_BN;
         const int auto_cap = (3 * h->cu_count / 2) / (((g.L + 15) / 16 + 1) * nct);
-        const int cap = h->gemm_regs_cols >= 0 ? h->gemm_regs_cols : (auto_cap > 1 ? auto_cap : 1);
+        const int cap = h->gemm_regs_cols >= 0 ? h->gemm_regs_cols : auto_cap;       // (0 at the reference's shipped size: 408 workgroups for a lone column)
         if (live_tiling && use_sym(h) && pl.tail_cols <= cap && 16 * (g.D + 2) * 8 <= 150 * 1024 &&
             ((g.N + GEMM_KC - 1) / GEMM_KC * GEMM_KC) % 64 == 0) pl.gemm = SOSRT_PLAN_GEMM_LIVE16_REGS;
     }
