@@ -540,6 +540,36 @@ def test_transport_over_the_dense_tilings_live_list_keeps_the_bits(case, monkeyp
     assert np.array_equal(a.I, b.I)                                            # bit for bit
 
 
+@pytest.mark.parametrize("B,groups", [(1, "1"), (7, "1"), (300, "2")])
+def test_single_slab_batches_through_the_new_contraction_paths(B, groups, monkeypatch):
+    """The single-slab geometry (I1_In:13-129: no aerosol rows, so no per-column slab descriptors and the group's operands offset by
+    the launcher) through the register-resident tile and through the dense tiling's live list, two column groups included: same
+    bits as with both switched off, and the first column against the oracle."""
+    L, N = 30, 64
+    rng = np.random.default_rng(B)
+    mu = inputs.direction_grid(N)
+    mu0 = rng.uniform(0.2, 1.0, B); alb = rng.uniform(0.6, 1.0, B); tstar = rng.choice([0.1, 0.3, 1.0, 2.0], B)
+    P = inputs.phase_function("hg", N, mu, 0.5, 0.7)[1]
+    P0 = np.stack([inputs.phase_function("hg", N, mu, m, 0.7)[0] for m in mu0])
+    tau = np.stack([np.linspace(0.0, t, L) for t in tstar])
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("SOSRT_GEMM_REGS", "0" if on == "0" else "64")
+        monkeypatch.setenv("SOSRT_DENSE_LIVE_LIST", on)
+        monkeypatch.setenv("SOSRT_GROUPS", groups)
+        s = Solver(L, N, max_batch=B, max_orders=200)
+        s.set_grid(mu); s.set_phase(P)
+        s.set_columns_single_slab(mu0, alb, tstar)
+        out[on] = s.solve(tau, P0)
+        s.close()
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a.n, b.n) and np.array_equal(a.status, b.status) and (a.status == 0).all()
+    assert np.array_equal(a.I, b.I)
+    ref = O.solve_single_slab(tau[0], mu, float(tstar[0]), float(mu0[0]), P0[0], P, float(alb[0]), N, literal=False)
+    assert int(b.n[0]) == ref.n
+    assert_close(b.I[0], ref.I, RTOL, "single slab, column 0")
+
+
 def test_a_refused_order_loop_launch_hands_the_orders_back():
     """The residency handshake of an order-loop launch, made to fail on purpose (mode 2: a grid of twice the device's CUs): every
     workgroup that is on the machine waits 4 ms for the ones that are not, one of them declares the launch NOT RESIDENT, nothing
