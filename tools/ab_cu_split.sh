@@ -1,3 +1,4 @@
+# (needs the order loop of tools/cu_split_order_loop.patch: git apply it and rebuild -- the library itself has no SOSRT_CU_SPLIT)
 # usage: bash tools/ab_cu_split.sh [bench args...] -> gpurun_out/ab_cu_split.log + digest: the two-group order loop with the kernels of the
 # dense orders on disjoint sets of CUs (SOSRT_CU_SPLIT = CUs of the contraction's part), against the shared-CU default, two rounds
 mkdir -p gpurun_out
