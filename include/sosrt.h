@@ -58,7 +58,8 @@ typedef struct sosrt_handle sosrt_t;
 const char* sosrt_last_error(void);
 /* 100 * major + minor of the ABI this library was built from.  101 (round 4): sosrt_set_stream(h, NULL) names the legacy default
  * stream (100 read NULL as "the handle's own stream"); the per-handle launch plan (sosrt_plan_launch) and the order loop that
- * runs several orders per launch (sosrt_set_order_loop) were added.  A binding checks sosrt_version() >= the SOSRT_VERSION it
+ * runs several orders per launch (sosrt_set_order_loop) were added (sosrt_plan_launch may answer SOSRT_PLAN_GEMM_LIVE16_REGS since the
+ * second half of that round).  A binding checks sosrt_version() >= the SOSRT_VERSION it
  * was written against. */
 #define SOSRT_VERSION 101
 int sosrt_version(void);
